@@ -1,0 +1,40 @@
+"""In-tree build of libcinema_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["api.hip", "siren.hip", "trilerp.hip", "loss.hip"]
+HEADERS = ["common.h", "gemm_engine.h", os.path.join("..", "..", "include", "cinema_hip.h")]
+OUT = os.path.join(_HERE, "libcinema_hip.so")
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (expected on PATH or at /opt/rocm/bin/hipcc)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + SOURCES
+    if verbose:
+        print("[cinema_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True)

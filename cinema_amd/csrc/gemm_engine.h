@@ -1,0 +1,297 @@
+// LDS-tiled MFMA mainloops shared by the SIREN kernels (gfx950).
+//
+// Orientation.  Every "NT" product is computed as C[f][n] = sum_k Wt[f][k] * X[n][k] with the
+// WEIGHTS as the MFMA A operand (rows = output features) and the ACTIVATIONS as the B operand
+// (columns = samples).  With the 16x16 accumulator map (col = lane & 15, row = 4*(lane>>4)+reg)
+// and the feature rows of each 64-row slab permuted on their way into LDS, a lane ends up
+// holding 16 CONSECUTIVE output features of one sample (acc[ft][st][r] <-> feature
+// 16*(lane>>4) + 4*ft + r, sample 16*st + (lane&15)), so epilogues read and write saved
+// activations with 16-byte vectors instead of 2-byte scalars.
+//
+// Workgroup = 256 threads = 4 waves (2 x 2), tile = 128 features x 128 samples, each wave
+// 64 x 64 = 4 x 4 MFMA tiles.  Double-buffered LDS, register-staged global loads issued one
+// k-tile ahead (issue early, write late), one barrier per k-tile.
+//   bf16: v_mfma_f32_16x16x32_bf16, k-tile 64, 128-B LDS rows with a 16-B-chunk XOR swizzle
+//         (conflict-free ds_read_b128).
+//   f32 : v_mfma_f32_16x16x4_f32 (exact f32), k-tile 16, 80-B LDS rows.
+//
+// The "TN" product C[h][k] = sum_n P[n][h] * Q[n][k] (weight gradients, reduction over the
+// samples) keeps both operands in their natural [n][feature] layout in LDS; bf16 fragments
+// come from ds_read_b64_tr_b16 (hardware transpose), f32 fragments are one element per lane.
+#pragma once
+#include "common.h"
+
+#define WG_THREADS 256
+
+template <typename T>
+struct Engine;
+
+// feature row (0..127 within the workgroup tile) -> LDS row: swap the two 2-bit fields
+// (f>>4)&3 and (f>>2)&3 inside each 64-row slab.
+__device__ __forceinline__ int perm_feature_row(int f) {
+  return (f & 0x43) | (((f >> 4) & 3) << 2) | (((f >> 2) & 3) << 4);
+}
+
+// ----------------------------------------------------------------------------------------
+// bf16
+// ----------------------------------------------------------------------------------------
+template <>
+struct Engine<bf16_t> {
+  static constexpr int BK = 64;                   // NT k-tile (elements)
+  static constexpr int NT_TILE = 128 * 128;       // bytes per operand tile (128 rows x 128 B)
+  static constexpr int NT_SMEM = 4 * NT_TILE;     // 2 operands x 2 buffers
+  static constexpr int BN = 64;                   // TN n-tile (samples)
+  static constexpr int TN_TILE = 64 * 256;        // 64 rows x 256 B (128 columns)
+  static constexpr int TN_SMEM = 4 * TN_TILE;
+
+  struct Stage { u32x4 a[4], b[4]; };
+
+  // A: weights [rowsA x ld] (row-clamped), B: activations [>=128 rows x ld]
+  __device__ static __forceinline__ void nt_load(Stage &s, const bf16_t *A, int ldA, int rowsA, const bf16_t *B,
+                                                 int ldB, int k0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 3, ch = q & 7;
+      const int ra = row < rowsA ? row : rowsA - 1;
+      s.a[it] = *reinterpret_cast<const u32x4 *>(A + (size_t)ra * ldA + k0 + ch * 8);
+      s.b[it] = *reinterpret_cast<const u32x4 *>(B + (size_t)row * ldB + k0 + ch * 8);
+    }
+  }
+  __device__ static __forceinline__ void nt_store(const Stage &s, char *sA, char *sB, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 3, ch = q & 7;
+      const int pr = perm_feature_row(row);
+      *reinterpret_cast<u32x4 *>(sA + pr * 128 + ((ch ^ ((pr >> 1) & 7)) << 4)) = s.a[it];
+      *reinterpret_cast<u32x4 *>(sB + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = s.b[it];
+    }
+  }
+  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const char *sA, const char *sB, int wf,
+                                                    int wn, int lane) {
+    const int i = lane & 15, gk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[4], b[4];
+      const int ch = kk * 4 + gk;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ra = wf * 64 + t * 16 + i;
+        a[t] = *reinterpret_cast<const bf16x8 *>(sA + ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4));
+        const int rb = wn * 64 + t * 16 + i;
+        b[t] = *reinterpret_cast<const bf16x8 *>(sB + rb * 128 + ((ch ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ft], b[st], acc[ft][st], 0, 0, 0);
+    }
+  }
+
+  // ---- TN ----
+  // P: [n][colsP] (ld ldP), tile columns h0..h0+127 (column-chunk clamped to the row), same for Q.
+  __device__ static __forceinline__ void tn_load(Stage &s, const bf16_t *P, int ldP, int h0, const bf16_t *Q, int ldQ,
+                                                 int c0, int n0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 4, ch = q & 15;
+      int hp = h0 + ch * 8; if (hp + 8 > ldP) hp = 0;
+      int cq = c0 + ch * 8; if (cq + 8 > ldQ) cq = 0;
+      s.a[it] = *reinterpret_cast<const u32x4 *>(P + (size_t)(n0 + row) * ldP + hp);
+      s.b[it] = *reinterpret_cast<const u32x4 *>(Q + (size_t)(n0 + row) * ldQ + cq);
+    }
+  }
+  __device__ static __forceinline__ int tn_off(int row, int colbyte) {
+    const int key = (row & 3) | (((row >> 3) & 1) << 2);
+    return row * 256 + ((((colbyte >> 4) ^ (key << 1)) << 4) | (colbyte & 15));
+  }
+  __device__ static __forceinline__ void tn_store(const Stage &s, char *sP, char *sQ, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 4, ch = q & 15;
+      const int off = tn_off(row, ch * 16);
+      *reinterpret_cast<u32x4 *>(sP + off) = s.a[it];
+      *reinterpret_cast<u32x4 *>(sQ + off) = s.b[it];
+    }
+  }
+  __device__ static __forceinline__ bf16x8 tr_frag(const char *tile, int nbase, int colbase, int lane) {
+    // lanes 16g..16g+15 fetch rows nbase+8g+{0..7} of 16 columns; lane 4q+p addresses row q, columns 4p..4p+3
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = nbase + 8 * g + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4 *)(tile + tn_off(r0, (colbase + 4 * p) * 2)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4 *)(tile + tn_off(r0 + 4, (colbase + 4 * p) * 2)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const char *sP, const char *sQ, int wh, int wk,
+                                                    int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = tr_frag(sP, kk * 32, wh * 64 + t * 16, lane);
+        b[t] = tr_frag(sQ, kk * 32, wk * 64 + t * 16, lane);
+      }
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------
+// f32 (exact): one element per lane per fragment
+// ----------------------------------------------------------------------------------------
+template <>
+struct Engine<float> {
+  static constexpr int BK = 16;
+  static constexpr int NT_ROW = 20;                       // floats per LDS row (16 + pad)
+  static constexpr int NT_TILE = 128 * NT_ROW * 4;
+  static constexpr int NT_SMEM = 4 * NT_TILE;
+  static constexpr int BN = 16;
+  static constexpr int TN_ROW = 144;                      // floats per LDS row (128 + pad)
+  static constexpr int TN_TILE = 16 * TN_ROW * 4;
+  static constexpr int TN_SMEM = 4 * TN_TILE;
+
+  struct Stage { f32x4 a[2], b[2]; };
+
+  __device__ static __forceinline__ void nt_load(Stage &s, const float *A, int ldA, int rowsA, const float *B,
+                                                 int ldB, int k0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 2, ch = q & 3;
+      const int ra = row < rowsA ? row : rowsA - 1;
+      s.a[it] = *reinterpret_cast<const f32x4 *>(A + (size_t)ra * ldA + k0 + ch * 4);
+      s.b[it] = *reinterpret_cast<const f32x4 *>(B + (size_t)row * ldB + k0 + ch * 4);
+    }
+  }
+  __device__ static __forceinline__ void nt_store(const Stage &s, char *sA, char *sB, int tid) {
+    float *fA = reinterpret_cast<float *>(sA), *fB = reinterpret_cast<float *>(sB);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 2, ch = q & 3;
+      *reinterpret_cast<f32x4 *>(fA + perm_feature_row(row) * NT_ROW + ch * 4) = s.a[it];
+      *reinterpret_cast<f32x4 *>(fB + row * NT_ROW + ch * 4) = s.b[it];
+    }
+  }
+  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const char *sA, const char *sB, int wf,
+                                                    int wn, int lane) {
+    const float *fA = reinterpret_cast<const float *>(sA), *fB = reinterpret_cast<const float *>(sB);
+    const int i = lane & 15, gk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = fA[(wf * 64 + t * 16 + i) * NT_ROW + kk * 4 + gk];
+        b[t] = fB[(wn * 64 + t * 16 + i) * NT_ROW + kk * 4 + gk];
+      }
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft], b[st], acc[ft][st], 0, 0, 0);
+    }
+  }
+
+  __device__ static __forceinline__ void tn_load(Stage &s, const float *P, int ldP, int h0, const float *Q, int ldQ,
+                                                 int c0, int n0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 5, ch = q & 31;
+      int hp = h0 + ch * 4; if (hp + 4 > ldP) hp = 0;
+      int cq = c0 + ch * 4; if (cq + 4 > ldQ) cq = 0;
+      s.a[it] = *reinterpret_cast<const f32x4 *>(P + (size_t)(n0 + row) * ldP + hp);
+      s.b[it] = *reinterpret_cast<const f32x4 *>(Q + (size_t)(n0 + row) * ldQ + cq);
+    }
+  }
+  __device__ static __forceinline__ void tn_store(const Stage &s, char *sP, char *sQ, int tid) {
+    float *fP = reinterpret_cast<float *>(sP), *fQ = reinterpret_cast<float *>(sQ);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = tid + WG_THREADS * it;
+      const int row = q >> 5, ch = q & 31;
+      *reinterpret_cast<f32x4 *>(fP + row * TN_ROW + ch * 4) = s.a[it];
+      *reinterpret_cast<f32x4 *>(fQ + row * TN_ROW + ch * 4) = s.b[it];
+    }
+  }
+  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const char *sP, const char *sQ, int wh, int wk,
+                                                    int lane) {
+    const float *fP = reinterpret_cast<const float *>(sP), *fQ = reinterpret_cast<const float *>(sQ);
+    const int i = lane & 15, gk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = fP[(kk * 4 + gk) * TN_ROW + wh * 64 + t * 16 + i];
+        b[t] = fQ[(kk * 4 + gk) * TN_ROW + wk * 64 + t * 16 + i];
+      }
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+    }
+  }
+};
+
+// acc += Wt[f0.., :K] * X[n0.., :K]^T over K (a multiple of Engine::BK).  All 256 threads call it.
+template <typename T>
+__device__ __forceinline__ void nt_mainloop(f32x4 (&acc)[4][4], const T *A, int ldA, int rowsA, const T *B, int ldB,
+                                            int K, char *smem) {
+  using E = Engine<T>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wf = wave >> 1, wn = wave & 1;
+  char *sA[2] = {smem, smem + 2 * E::NT_TILE};
+  char *sB[2] = {smem + E::NT_TILE, smem + 3 * E::NT_TILE};
+  typename E::Stage st;
+  const int nt = K / E::BK;
+  __syncthreads();  // LDS may still be read by a previous mainloop of this workgroup
+  E::nt_load(st, A, ldA, rowsA, B, ldB, 0, tid);
+  E::nt_store(st, sA[0], sB[0], tid);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) E::nt_load(st, A, ldA, rowsA, B, ldB, (t + 1) * E::BK, tid);
+    E::nt_compute(acc, sA[cur], sB[cur], wf, wn, lane);
+    if (t + 1 < nt) E::nt_store(st, sA[cur ^ 1], sB[cur ^ 1], tid);
+    __syncthreads();
+  }
+}
+
+// acc += P[nbeg..nend, h0..]^T * Q[nbeg..nend, c0..]; nbeg/nend multiples of Engine::BN.
+template <typename T>
+__device__ __forceinline__ void tn_mainloop(f32x4 (&acc)[4][4], const T *P, int ldP, int h0, const T *Q, int ldQ,
+                                            int c0, int nbeg, int nend, char *smem) {
+  using E = Engine<T>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wh = wave >> 1, wk = wave & 1;
+  char *sP[2] = {smem, smem + 2 * E::TN_TILE};
+  char *sQ[2] = {smem + E::TN_TILE, smem + 3 * E::TN_TILE};
+  typename E::Stage st;
+  if (nbeg >= nend) return;  // uniform per workgroup
+  E::tn_load(st, P, ldP, h0, Q, ldQ, c0, nbeg, tid);
+  E::tn_store(st, sP[0], sQ[0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int n0 = nbeg; n0 < nend; n0 += E::BN) {
+    const bool more = n0 + E::BN < nend;
+    if (more) E::tn_load(st, P, ldP, h0, Q, ldQ, c0, n0 + E::BN, tid);
+    E::tn_compute(acc, sP[cur], sQ[cur], wh, wk, lane);
+    if (more) E::tn_store(st, sP[cur ^ 1], sQ[cur ^ 1], tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+}

@@ -1,0 +1,210 @@
+// K3: ground-truth sampling fused with the loss reduction and dLoss/dOutput, plus the
+// dense-inference epilogue.
+// Reference arithmetic: utils.py:77-104 (Criterion), data_loading/dataset.py:87-89 (integer
+// voxel gather of every modality), models/inr_decoder.py:50-57 (inference post-processing).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void k_class_weight_sum(const float *target, int tcols, const int64_t *voxel, const int32_t *subj,
+                                   const uint8_t *labels, long V, long N, int n_cls, const float *class_w, float *sums) {
+  float acc = 0.f;
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    int y = target ? (int)target[n * tcols + tcols - 1] : (int)labels[(long)subj[n] * V + voxel[n]];
+    y = y < 0 ? 0 : (y >= n_cls ? n_cls - 1 : y);
+    acc += class_w[y];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(sums + 2, acc);
+}
+
+struct LossArgs {
+  const float *out; const float *target; const int64_t *voxel; const int32_t *subj; const float *intens;
+  const uint8_t *labels; long V, N, Npad; int sr_dims, n_cls, metric; const float *class_w;
+  float sr_scale, seg_scale; float *sums; float *dout; float *target_out; int wsum_on_device;
+};
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void k_sample_loss(LossArgs a) {
+  const int od = a.sr_dims + a.n_cls;
+  const int tcols = a.sr_dims + 1;
+  float acc_sr = 0.f, acc_ce = 0.f, acc_w = 0.f;
+  const float wtot = a.wsum_on_device ? a.sums[2] : (float)a.N;
+  const float inv_sr = a.sr_scale / ((float)a.N * (float)a.sr_dims);
+  const float inv_w = wtot > 0.f ? a.seg_scale / wtot : 0.f;
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < a.Npad; n += (long)gridDim.x * blockDim.x) {
+    float *drow = a.dout + n * od;
+    if (n >= a.N) {
+      for (int j = 0; j < od; ++j) drow[j] = 0.f;
+      continue;
+    }
+    const float *orow = a.out + n * od;
+    int y;
+    long vbase = 0;
+    if (a.target) {
+      y = (int)a.target[n * tcols + a.sr_dims];
+    } else {
+      vbase = (long)a.subj[n] * a.V + a.voxel[n];
+      y = (int)a.labels[vbase];
+    }
+    for (int m = 0; m < a.sr_dims; ++m) {
+      const float t = a.target ? a.target[n * tcols + m] : a.intens[vbase * a.sr_dims + m];
+      if (a.target_out) a.target_out[n * tcols + m] = t;
+      const float d = orow[m] - t;
+      if (a.metric == 0) {
+        acc_sr += d * d;
+        drow[m] = 2.f * d * inv_sr;
+      } else {
+        acc_sr += fabsf(d);
+        drow[m] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_sr;
+      }
+    }
+    if (a.target_out) a.target_out[n * tcols + a.sr_dims] = (float)y;
+    if (a.seg_scale > 0.f) {
+      y = y < 0 ? 0 : (y >= a.n_cls ? a.n_cls - 1 : y);
+      float lg[MAXC];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        lg[j] = j < a.n_cls ? orow[a.sr_dims + j] : -INFINITY;
+        mx = fmaxf(mx, lg[j]);
+      }
+      float se = 0.f, ly = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const float e = j < a.n_cls ? expf(lg[j] - mx) : 0.f;
+        se += e;
+        lg[j] = e;
+      }
+      ly = orow[a.sr_dims + y];
+      const float lse = mx + logf(se);
+      const float w = a.class_w ? a.class_w[y] : 1.f;
+      acc_ce += w * (lse - ly);
+      acc_w += w;
+      const float k = w * inv_w, inv_se = 1.f / se;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        if (j < a.n_cls) drow[a.sr_dims + j] = k * (lg[j] * inv_se - (j == y ? 1.f : 0.f));
+    } else {
+      for (int j = 0; j < a.n_cls; ++j) drow[a.sr_dims + j] = 0.f;
+    }
+  }
+  __shared__ float red[3][4];
+  acc_sr = wave_sum(acc_sr);
+  acc_ce = wave_sum(acc_ce);
+  acc_w = wave_sum(acc_w);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = acc_sr; red[1][wave] = acc_ce; red[2][wave] = acc_w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(a.sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(a.sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    atomicAdd(a.sums + 3, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+  }
+}
+
+// ---- dense-inference epilogue ----
+__global__ void k_infer_minmax(const float *out, long G, int od, int sr, float *minmax) {
+  // values are clamped to [0,1] first, so unsigned-int ordering equals float ordering
+  float mn[8], mx[8];
+  for (int m = 0; m < 8; ++m) { mn[m] = 1.f; mx[m] = 0.f; }
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < G; n += (long)gridDim.x * blockDim.x)
+    for (int m = 0; m < sr; ++m) {
+      const float v = fminf(fmaxf(out[n * od + m], 0.f), 1.f);
+      mn[m] = fminf(mn[m], v);
+      mx[m] = fmaxf(mx[m], v);
+    }
+  for (int m = 0; m < sr; ++m) {
+    float a = mn[m], b = mx[m];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+      a = fminf(a, __shfl_xor(a, k, 64));
+      b = fmaxf(b, __shfl_xor(b, k, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(reinterpret_cast<unsigned int *>(minmax) + m, __float_as_uint(a));
+      atomicMax(reinterpret_cast<unsigned int *>(minmax) + sr + m, __float_as_uint(b));
+    }
+  }
+}
+
+template <int MAXC>
+__global__ void k_infer_finish(const float *out, long G, int od, int sr, const float *minmax, float *vol) {
+  const int ncls = od - sr, vc = sr + 1 + ncls;
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < G; n += (long)gridDim.x * blockDim.x) {
+    const float *o = out + n * od;
+    float *v = vol + n * vc;
+    for (int m = 0; m < sr; ++m) {
+      const float x = fminf(fmaxf(o[m], 0.f), 1.f);
+      v[m] = (x - minmax[m]) / (minmax[sr + m] - minmax[m]);   // 0/0 -> NaN like the reference
+    }
+    float lg[MAXC], mx = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      lg[j] = j < ncls ? o[sr + j] : -INFINITY;
+      if (lg[j] > mx) { mx = lg[j]; arg = j; }   // first maximum wins, like torch.argmax
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { lg[j] = j < ncls ? expf(lg[j] - mx) : 0.f; se += lg[j]; }
+    v[sr] = (float)arg;
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < ncls) v[sr + 1 + j] = lg[j] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                                          const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                                          int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                                          float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                                          void *stream) {
+  CINEMA_REQUIRE(out && sums && dout, "cinema_sample_loss_fwd_bwd: null argument");
+  CINEMA_REQUIRE(target || (voxel && subj && intens && labels), "cinema_sample_loss_fwd_bwd: need a dense target or volumes");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N, "cinema_sample_loss_fwd_bwd: bad sizes");
+  CINEMA_REQUIRE(sr_dims >= 1 && sr_dims <= 8 && n_cls >= 1 && n_cls <= 16, "unsupported out_dim split %d + %d", sr_dims, n_cls);
+  CINEMA_REQUIRE(loss_metric == 0 || loss_metric == 1, "loss_metric must be 0 (mse) or 1 (l1)");
+  hipStream_t s = (hipStream_t)stream;
+  CINEMA_CHECK_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(float), s));
+  const unsigned grid = (unsigned)std::min<long>((Npad + 255) / 256, 2048);
+  const int wdev = (class_w != nullptr && seg_scale > 0.f) ? 1 : 0;
+  if (wdev) {
+    hipLaunchKernelGGL(k_class_weight_sum, dim3(grid), dim3(256), 0, s, target, sr_dims + 1, voxel, subj, labels, (long)V,
+                       (long)N, n_cls, class_w, sums);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  LossArgs a = {out, target, voxel, subj, intens, labels, (long)V, (long)N, (long)Npad, sr_dims, n_cls, loss_metric, class_w,
+                sr_scale, seg_scale, sums, dout, target_out, wdev};
+  hipLaunchKernelGGL(k_sample_loss<16>, dim3(grid), dim3(256), 0, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_infer_minmax(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, float *minmax, void *stream) {
+  CINEMA_REQUIRE(out && minmax && G >= 1 && sr_dims >= 1 && sr_dims <= 8 && out_dim > sr_dims, "cinema_infer_minmax: bad argument");
+  const unsigned grid = (unsigned)std::min<long>((G + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_infer_minmax, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long)G, out_dim, sr_dims, minmax);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_infer_finish(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax,
+                                   float *vol, void *stream) {
+  CINEMA_REQUIRE(out && minmax && vol && G >= 1 && sr_dims >= 1 && out_dim > sr_dims && out_dim - sr_dims <= 16,
+                 "cinema_infer_finish: bad argument");
+  const unsigned grid = (unsigned)std::min<long>((G + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_infer_finish<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long)G, out_dim, sr_dims, minmax, vol);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}

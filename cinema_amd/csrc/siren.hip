@@ -1,0 +1,886 @@
+// SIREN stack kernels (forward, backward, weight gradients, packing) for gfx950.
+// Reference arithmetic: models/siren.py:26-36 (SineLayer.forward), :59-61 (Siren.forward).
+#include "gemm_engine.h"
+#include <algorithm>
+
+namespace {
+
+// ----------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void sincos_t(float a, float &s, float &c);
+template <> __device__ __forceinline__ void sincos_t<float>(float a, float &s, float &c) { sincosf(a, &s, &c); }
+template <> __device__ __forceinline__ void sincos_t<bf16_t>(float a, float &s, float &c) {
+  s = __sinf(a);
+  c = __cosf(a);
+}
+
+struct TileCtx {
+  int f0, n0;          // workgroup tile origin (features, samples)
+  int lane, wf, wn, g, i;
+  int fb;              // first of this lane's 16 consecutive features
+  int nrow[4];         // this lane's sample row for each sample tile st
+};
+
+__device__ __forceinline__ TileCtx make_ctx(int tiles_f) {
+  TileCtx c;
+  const int nwg = gridDim.x;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  c.f0 = (id % tiles_f) * 128;
+  c.n0 = (id / tiles_f) * 128;
+  const int tid = threadIdx.x;
+  c.lane = tid & 63;
+  const int wave = tid >> 6;
+  c.wf = wave >> 1;
+  c.wn = wave & 1;
+  c.g = c.lane >> 4;
+  c.i = c.lane & 15;
+  c.fb = c.f0 + c.wf * 64 + 16 * c.g;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) c.nrow[st] = c.n0 + c.wn * 64 + 16 * st + c.i;
+  return c;
+}
+
+__device__ __forceinline__ void acc_fill(f32x4 (&acc)[4][4], const float (&v)[16]) {
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 x = {v[4 * ft], v[4 * ft + 1], v[4 * ft + 2], v[4 * ft + 3]};
+      acc[ft][st] = x;
+    }
+}
+
+// v[j] = p[fb + j] for fb + j < limit, else 0
+__device__ __forceinline__ void load_feature_vec(const float *p, int fb, int limit, float (&v)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = (p != nullptr && fb + j < limit) ? p[fb + j] : 0.f;
+}
+
+// acc[f][n] += sum_{k<ks} Ws[f*sf + k*sk] * Xs[n*ldx + k]   (fp32 VALU path for K <= 16)
+__device__ __forceinline__ void smallk_accumulate(f32x4 (&acc)[4][4], const TileCtx &c, const float *Xs, int ldx,
+                                                  int ks, const float *Ws, int sf, int sk, int flimit) {
+  for (int k = 0; k < ks; ++k) {
+    float xv[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) xv[st] = Xs[(size_t)c.nrow[st] * ldx + k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float w = (c.fb + j < flimit) ? Ws[(size_t)(c.fb + j) * sf + (size_t)k * sk] : 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w * xv[st];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// forward: one sine layer (optionally FiLM-modulated)        siren.py:26-36
+// ----------------------------------------------------------------------------------------
+struct FwdArgs {
+  const void *X; int ldx;                                     // [Npad x K] T          (MFMA input)
+  const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;   // small-K fp32 input
+  const void *W; int K; int rowsW;                            // packed [HP x K] T
+  const float *bias;                                          // [H]
+  const void *LAT; int LP;                                    // [Npad x LP] T
+  const void *Wls; const void *Wlt;                           // packed [HP x LP] T
+  const float *bias_l;                                        // [2H]
+  void *Y; void *C; void *Z; void *S; int ldo; int HP;        // outputs [Npad x HP] T
+  int H; float omega; int tiles_f;
+};
+
+template <typename T, bool MOD, bool SMALLK>
+__global__ __launch_bounds__(WG_THREADS) void k_layer_fwd(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileCtx c = make_ctx(a.tiles_f);
+  f32x4 accZ[4][4];
+  float v[16];
+  load_feature_vec(a.bias, c.fb, a.H, v);
+  acc_fill(accZ, v);
+  if constexpr (SMALLK) {
+    smallk_accumulate(accZ, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.H);
+  } else {
+    nt_mainloop<T>(accZ, (const T *)a.W + (size_t)c.f0 * a.K, a.K, a.rowsW - c.f0, (const T *)a.X + (size_t)c.n0 * a.ldx,
+                   a.ldx, a.K, smem);
+  }
+  const bool fvalid = c.fb < a.HP;
+  if constexpr (MOD) {
+    f32x4 accS[4][4];
+    load_feature_vec(a.bias_l, c.fb, a.H, v);
+    acc_fill(accS, v);
+    nt_mainloop<T>(accS, (const T *)a.Wls + (size_t)c.f0 * a.LP, a.LP, a.rowsW - c.f0,
+                   (const T *)a.LAT + (size_t)c.n0 * a.LP, a.LP, a.LP, smem);
+    float bt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bt[j] = (c.fb + j < a.H) ? a.bias_l[a.H + c.fb + j] : 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float zv[16], sv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { zv[j] = accZ[j >> 2][st][j & 3]; sv[j] = accS[j >> 2][st][j & 3]; }
+      if (fvalid) {
+        store16((T *)a.Z + (size_t)c.nrow[st] * a.ldo + c.fb, zv);
+        store16((T *)a.S + (size_t)c.nrow[st] * a.ldo + c.fb, sv);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accZ[j >> 2][st][j & 3] = a.omega * zv[j] * sv[j] + bt[j];
+    }
+    nt_mainloop<T>(accZ, (const T *)a.Wlt + (size_t)c.f0 * a.LP, a.LP, a.rowsW - c.f0,
+                   (const T *)a.LAT + (size_t)c.n0 * a.LP, a.LP, a.LP, smem);
+  }
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    float yv[16], cv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float ph = accZ[j >> 2][st][j & 3];
+      if constexpr (!MOD) ph *= a.omega;
+      sincos_t<T>(ph, yv[j], cv[j]);
+    }
+    if (fvalid) {
+      store16((T *)a.Y + (size_t)c.nrow[st] * a.ldo + c.fb, yv);
+      store16((T *)a.C + (size_t)c.nrow[st] * a.ldo + c.fb, cv);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// backward chain: dy = G * W (or the small-K product with final_linear), then the elementwise
+// backward of the layer whose output dy refers to; writes dz (, ds, dt) and the bias gradients.
+// ----------------------------------------------------------------------------------------
+struct BwdArgs {
+  const void *G; int ldg;                 // [Npad x Kred] T : dz of the layer above
+  const void *WT; int Kred; int rowsWT;   // packed W^T [HP x Kred] T
+  const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;   // top of the chain: dOut, final_linear
+  const void *C; const void *Z; const void *S; int ldo; int HP;
+  void *DZ; void *DS; void *DT;
+  float omega; int H;
+  float *db; float *dbl;                  // grads of linear.bias [H], linear_lats.bias [2H] (atomics); may be NULL
+  const float *coords; int in_dim; const float *W0; float *dW0; float *dcoords;   // FIRST only
+  int tiles_f;
+};
+
+template <typename T, bool MOD, bool SMALLK, bool FIRST>
+__global__ __launch_bounds__(WG_THREADS) void k_layer_bwd(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileCtx c = make_ctx(a.tiles_f);
+  f32x4 acc[4][4];
+  {
+    float zero[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zero[j] = 0.f;
+    acc_fill(acc, zero);
+  }
+  if constexpr (SMALLK) {
+    smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.H);
+  } else {
+    nt_mainloop<T>(acc, (const T *)a.WT + (size_t)c.f0 * a.Kred, a.Kred, a.rowsWT - c.f0,
+                   (const T *)a.G + (size_t)c.n0 * a.ldg, a.ldg, a.Kred, smem);
+  }
+  const bool fvalid = c.fb < a.HP;
+  float sum_z[16], sum_s[16], sum_t[16], sum_w[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sum_z[j] = sum_s[j] = sum_t[j] = 0.f;
+    sum_w[0][j] = sum_w[1][j] = sum_w[2][j] = 0.f;
+  }
+  float w0[3][16];
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        w0[k][j] = (k < a.in_dim && c.fb + j < a.H) ? a.W0[(size_t)(c.fb + j) * a.in_dim + k] : 0.f;
+  }
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const size_t row = (size_t)c.nrow[st] * a.ldo + c.fb;
+    float cv[16], dz[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { cv[j] = 0.f; }
+    if (fvalid) load16((const T *)a.C + row, cv);
+    if constexpr (MOD) {
+      float zv[16], sv[16], ds[16], dt[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { zv[j] = 0.f; sv[j] = 0.f; }
+      if (fvalid) {
+        load16((const T *)a.Z + row, zv);
+        load16((const T *)a.S + row, sv);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float gq = acc[j >> 2][st][j & 3] * cv[j];
+        dt[j] = gq;
+        dz[j] = a.omega * gq * sv[j];
+        ds[j] = a.omega * gq * zv[j];
+        sum_s[j] += ds[j];
+        sum_t[j] += dt[j];
+      }
+      if (fvalid) {
+        store16((T *)a.DS + row, ds);
+        store16((T *)a.DT + row, dt);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dz[j] = a.omega * acc[j >> 2][st][j & 3] * cv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum_z[j] += dz[j];
+    if (fvalid) store16((T *)a.DZ + row, dz);
+    if constexpr (FIRST) {
+      float xk[3], dc[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        xk[k] = (k < a.in_dim) ? a.coords[(size_t)c.nrow[st] * a.in_dim + k] : 0.f;
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          sum_w[k][j] += dz[j] * xk[k];
+          p += dz[j] * w0[k][j];
+        }
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        dc[k] = p;
+      }
+      if (c.g == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < a.in_dim) atomicAdd(a.dcoords + (size_t)c.nrow[st] * a.in_dim + k, dc[k]);
+      }
+    }
+  }
+  // column sums over the 64 samples of this wave -> bias gradients
+  const int fi = c.fb + reduce16_index(c.i);
+  if (a.db != nullptr) {
+    const float tz = reduce16_scatter(sum_z, c.lane);
+    if (fi < a.H) atomicAdd(a.db + fi, tz);
+    if constexpr (MOD) {
+      const float ts = reduce16_scatter(sum_s, c.lane);
+      const float tt = reduce16_scatter(sum_t, c.lane);
+      if (fi < a.H) {
+        atomicAdd(a.dbl + fi, ts);
+        atomicAdd(a.dbl + a.H + fi, tt);
+      }
+    }
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float tw = reduce16_scatter(sum_w[k], c.lane);
+        if (k < a.in_dim && fi < a.H) atomicAdd(a.dW0 + (size_t)fi * a.in_dim + k, tw);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// d lat = sum over modulated layers (ds * Wl_scale + dt * Wl_shift) + dOut * Wf[:, H:]
+// ----------------------------------------------------------------------------------------
+struct DlatSeg { const void *Wt; const void *G; int K; };
+struct DlatArgs {
+  DlatSeg seg[2 * CINEMA_MAX_LAYERS];
+  int nseg;
+  const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;
+  int lat; int LP; int ldg;
+  float *out; int tiles_f;
+};
+
+template <typename T>
+__global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileCtx c = make_ctx(a.tiles_f);
+  f32x4 acc[4][4];
+  {
+    float zero[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zero[j] = 0.f;
+    acc_fill(acc, zero);
+  }
+  smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
+  for (int s = 0; s < a.nseg; ++s) {
+    const DlatSeg sg = a.seg[s];
+    nt_mainloop<T>(acc, (const T *)sg.Wt + (size_t)c.f0 * sg.K, sg.K, a.LP - c.f0, (const T *)sg.G + (size_t)c.n0 * a.ldg,
+                   a.ldg, sg.K, smem);
+  }
+  if (c.fb < a.LP) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = acc[j >> 2][st][j & 3];
+      store16(a.out + (size_t)c.nrow[st] * a.LP + c.fb, v);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// grouped weight-gradient GEMMs: dW[h][k] += sum_n P[n][h] * Q[n][k]
+// ----------------------------------------------------------------------------------------
+struct DwProb { const void *P; const void *Q; float *out; int ldp, ldq, ldo, M, K, tk; };
+struct DwArgs {
+  DwProb p[3 * CINEMA_MAX_LAYERS];
+  int tile_start[3 * CINEMA_MAX_LAYERS + 1];
+  int nprob, splitk, Npad;
+};
+
+template <typename T>
+__global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using E = Engine<T>;
+  const int bid = blockIdx.x;
+  const int tile = bid / a.splitk, split = bid - tile * a.splitk;
+  int pi = 0;
+  while (pi + 1 < a.nprob && tile >= a.tile_start[pi + 1]) ++pi;
+  const DwProb pr = a.p[pi];
+  const int t = tile - a.tile_start[pi];
+  const int h0 = (t / pr.tk) * 128, c0 = (t % pr.tk) * 128;
+  const int ntile = a.Npad / E::BN;
+  const int nbeg = (int)((long)ntile * split / a.splitk) * E::BN;
+  const int nend = (int)((long)ntile * (split + 1) / a.splitk) * E::BN;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
+  tn_mainloop<T>(acc, (const T *)pr.P, pr.ldp, h0, (const T *)pr.Q, pr.ldq, c0, nbeg, nend, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wh = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int col = c0 + wk * 64 + kt * 16 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = h0 + wh * 64 + ht * 16 + 4 * g + r;
+        if (row < pr.M && col < pr.K) atomicAdd(pr.out + (size_t)row * pr.ldo + col, acc[ht][kt][r]);
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// final linear (siren.py:61):  out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]
+// one wave per 16 samples, weights (padded to 16 rows) staged once per workgroup in LDS
+// ----------------------------------------------------------------------------------------
+struct FinalFwdArgs {
+  const void *X; int ldx; int HP; const void *LAT; int LP; const void *Wf;  // Wf packed [16 x (HP+LP)] T
+  const float *bias; int out_dim; float *out; int Npad;
+};
+
+template <typename T> struct FinalK;
+template <> struct FinalK<bf16_t> { static constexpr int STEP = 32; static constexpr int PADB = 16; };
+template <> struct FinalK<float> { static constexpr int STEP = 16; static constexpr int PADB = 16; };
+
+template <typename T>
+__global__ __launch_bounds__(WG_THREADS) void k_final_fwd(FinalFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KT = a.HP + a.LP;
+  const int rowbytes = KT * (int)sizeof(T) + FinalK<T>::PADB;
+  // stage weights: 16 rows x KT elements, 16-B chunks
+  const int chunks_per_row = KT * (int)sizeof(T) / 16;
+  for (int q = threadIdx.x; q < 16 * chunks_per_row; q += WG_THREADS) {
+    const int r = q / chunks_per_row, ch = q - r * chunks_per_row;
+    *reinterpret_cast<u32x4 *>(smem + r * rowbytes + ch * 16) =
+        *reinterpret_cast<const u32x4 *>((const char *)a.Wf + ((size_t)r * KT * sizeof(T)) + ch * 16);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int ntiles = a.Npad / 16;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int n = tile * 16 + i;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+      const T *src = part == 0 ? (const T *)a.X + (size_t)n * a.ldx : (const T *)a.LAT + (size_t)n * a.LP;
+      const int klen = part == 0 ? a.HP : a.LP;
+      const int kofs = part == 0 ? 0 : a.HP;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll 4
+        for (int k = 0; k < klen; k += 32) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8 *>(src + k + 8 * g);
+          const bf16x8 w = *reinterpret_cast<const bf16x8 *>(smem + i * rowbytes + (kofs + k + 8 * g) * 2);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll 2
+        for (int k = 0; k < klen; k += 16) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(src + k + 4 * g);
+          const f32x4 w = *reinterpret_cast<const f32x4 *>(smem + i * rowbytes + (kofs + k + 4 * g) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], b[j], acc, 0, 0, 0);
+        }
+      }
+    }
+    // acc[r] <-> output o = 4g + r of sample n
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * g + r;
+      if (o < a.out_dim) a.out[(size_t)n * a.out_dim + o] = acc[r] + a.bias[o];
+    }
+  }
+}
+
+// final_linear weight / bias gradients: dWf[o][k] = sum_n dOut[n][o] * [x_L | lat][n][k]
+struct FinalBwdArgs {
+  const void *X; int ldx; int H; const void *LAT; int LP; int lat;
+  const float *dout; int out_dim; float *dWf; float *dbf; int Npad;
+};
+
+template <typename T>
+__global__ __launch_bounds__(WG_THREADS) void k_final_bwd_dw(FinalBwdArgs a) {
+  __shared__ float sd[32 * 16];
+  const int KT = a.H + a.lat;
+  const int rows_per = (a.Npad + gridDim.x - 1) / gridDim.x;
+  const int nbeg = blockIdx.x * rows_per;
+  const int nend = min(a.Npad, nbeg + rows_per);
+  constexpr int MAXC = 4;  // columns per thread: supports H + lat <= 1024 per pass
+  for (int cbase = 0; cbase < KT; cbase += WG_THREADS * MAXC) {
+    float acc[MAXC][16];
+#pragma unroll
+    for (int m = 0; m < MAXC; ++m)
+#pragma unroll
+      for (int o = 0; o < 16; ++o) acc[m][o] = 0.f;
+    for (int nb = nbeg; nb < nend; nb += 32) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < 32 * 16; q += WG_THREADS) {
+        const int r = q >> 4, o = q & 15;
+        sd[q] = (nb + r < nend && o < a.out_dim) ? a.dout[(size_t)(nb + r) * a.out_dim + o] : 0.f;
+      }
+      __syncthreads();
+      const int rmax = min(32, nend - nb);
+      for (int r = 0; r < rmax; ++r) {
+#pragma unroll
+        for (int m = 0; m < MAXC; ++m) {
+          const int col = cbase + threadIdx.x + WG_THREADS * m;
+          if (col < KT) {
+            const float x = col < a.H ? to_f32(((const T *)a.X)[(size_t)(nb + r) * a.ldx + col])
+                                      : to_f32(((const T *)a.LAT)[(size_t)(nb + r) * a.LP + (col - a.H)]);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[m][o] += sd[r * 16 + o] * x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXC; ++m) {
+      const int col = cbase + threadIdx.x + WG_THREADS * m;
+      if (col < KT) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (o < a.out_dim) atomicAdd(a.dWf + (size_t)o * KT + col, acc[m][o]);
+      }
+    }
+  }
+  // bias gradient: threads 0..15 sum their column over this block's rows
+  if (threadIdx.x < a.out_dim) {
+    float s = 0.f;
+    for (int n = nbeg; n < nend; ++n) s += a.dout[(size_t)n * a.out_dim + threadIdx.x];
+    atomicAdd(a.dbf + threadIdx.x, s);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// packing: fp32 master weights -> zero-padded T copies (optionally transposed)
+// ----------------------------------------------------------------------------------------
+struct PackJob { const float *src; long dst; int rows, cols, ld, rowsP, colsP, transpose; };
+#define PACK_MAX_JOBS 64
+struct PackArgs { PackJob job[PACK_MAX_JOBS]; int njobs; void *packed; };
+
+template <typename T>
+__global__ void k_pack(PackArgs a) {
+  const PackJob j = a.job[blockIdx.y];
+  T *dst = (T *)a.packed + j.dst;
+  const long total = (long)j.rowsP * j.colsP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / j.colsP), cc = (int)(e - (long)r * j.colsP);
+    // destination element (r, cc) of a [rowsP x colsP] matrix; source is (r, cc) or (cc, r)
+    const int sr = j.transpose ? cc : r, sc = j.transpose ? r : cc;
+    const float v = (sr < j.rows && sc < j.cols) ? j.src[(size_t)sr * j.ld + sc] : 0.f;
+    dst[e] = (T)v;
+  }
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <typename T>
+int set_smem_attr(const void *fn, int bytes) {
+  if (bytes > 48 * 1024) {
+    CINEMA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ========================================================================================
+// host side
+// ========================================================================================
+extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
+  CINEMA_REQUIRE(d != nullptr, "cinema_siren_plan: null descriptor");
+  CINEMA_REQUIRE(d->n_layers >= 1 && d->n_layers <= CINEMA_MAX_LAYERS, "n_layers %d out of range [1,%d]", d->n_layers,
+                 CINEMA_MAX_LAYERS);
+  CINEMA_REQUIRE(d->in_dim >= 1 && d->in_dim <= 3, "in_dim %d unsupported (1..3)", d->in_dim);
+  CINEMA_REQUIRE(d->hidden >= 16 && d->hidden % 16 == 0, "hidden_size %d must be a positive multiple of 16", d->hidden);
+  CINEMA_REQUIRE(d->lat >= 1, "lat_size %d must be >= 1", d->lat);
+  CINEMA_REQUIRE(d->out_dim >= 1 && d->out_dim <= 16, "sum(out_dim) = %d unsupported (1..16)", d->out_dim);
+  CINEMA_REQUIRE(d->precision == CINEMA_PREC_F32 || d->precision == CINEMA_PREC_BF16, "bad precision %d", d->precision);
+  const int H = d->hidden, L = d->lat;
+  d->HP = round_up(H, 64);
+  d->LP = round_up(L, 64);
+  const long HP = d->HP, LP = d->LP;
+  // flat fp32 parameter layout = state_dict order of the reference Siren
+  long off = 0;
+  d->off_wf = off; off += (long)d->out_dim * (H + L);
+  d->off_bf = off; off += d->out_dim;
+  long pk = 0;
+  int sv = 0, gb = 0;
+  for (int i = 0; i < CINEMA_MAX_LAYERS; ++i) {
+    d->off_w[i] = d->off_b[i] = d->off_wl[i] = d->off_bl[i] = -1;
+    d->pk_w[i] = d->pk_wt[i] = d->pk_wls[i] = d->pk_wlt[i] = d->pk_wlsT[i] = d->pk_wltT[i] = -1;
+    d->sv_y[i] = d->sv_c[i] = d->sv_z[i] = d->sv_s[i] = -1;
+    d->gb_z[i] = d->gb_s[i] = d->gb_t[i] = -1;
+  }
+  for (int i = 0; i < d->n_layers; ++i) {
+    const int fan_in = i == 0 ? d->in_dim : H;
+    const bool mod = (d->modulated_mask >> i) & 1u;
+    d->off_w[i] = off; off += (long)H * fan_in;
+    d->off_b[i] = off; off += H;
+    if (mod) {
+      d->off_wl[i] = off; off += 2L * H * L;
+      d->off_bl[i] = off; off += 2L * H;
+    }
+    if (i > 0) {
+      d->pk_w[i] = pk; pk += HP * HP;
+      d->pk_wt[i] = pk; pk += HP * HP;
+    }
+    if (mod) {
+      d->pk_wls[i] = pk; pk += HP * LP;
+      d->pk_wlt[i] = pk; pk += HP * LP;
+      d->pk_wlsT[i] = pk; pk += LP * HP;
+      d->pk_wltT[i] = pk; pk += LP * HP;
+    }
+    d->sv_y[i] = sv++;
+    d->sv_c[i] = sv++;
+    d->gb_z[i] = gb++;
+    if (mod) {
+      d->sv_z[i] = sv++;
+      d->sv_s[i] = sv++;
+      d->gb_s[i] = gb++;
+      d->gb_t[i] = gb++;
+    }
+  }
+  d->pk_wf = pk; pk += 16L * (HP + LP);
+  d->n_params = off;
+  d->pk_total = pk;
+  d->n_saved = sv;
+  d->n_gbuf = gb;
+  return 0;
+}
+
+template <typename T>
+static int pack_impl(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
+  PackArgs a;
+  int nj = 0;
+  const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP;
+  a.packed = packed;
+  auto flush = [&]() -> int {
+    if (nj == 0) return 0;
+    a.njobs = nj;
+    hipLaunchKernelGGL((k_pack<T>), dim3(64, nj), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+    nj = 0;
+    return 0;
+  };
+  auto add = [&](const float *src, long dst, int rows, int cols, int ld, int rowsP, int colsP, int tr) -> int {
+    PackJob j = {src, dst, rows, cols, ld, rowsP, colsP, tr};
+    a.job[nj++] = j;
+    return nj == PACK_MAX_JOBS ? flush() : 0;
+  };
+  for (int i = 0; i < d->n_layers; ++i) {
+    if (i > 0) {
+      if (int rc = add(params + d->off_w[i], d->pk_w[i], H, H, H, HP, HP, 0)) return rc;
+      if (int rc = add(params + d->off_w[i], d->pk_wt[i], H, H, H, HP, HP, 1)) return rc;
+    }
+    if ((d->modulated_mask >> i) & 1u) {
+      const float *wl = params + d->off_wl[i];
+      if (int rc = add(wl, d->pk_wls[i], H, L, L, HP, LP, 0)) return rc;
+      if (int rc = add(wl + (size_t)H * L, d->pk_wlt[i], H, L, L, HP, LP, 0)) return rc;
+      if (int rc = add(wl, d->pk_wlsT[i], H, L, L, LP, HP, 1)) return rc;
+      if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
+    }
+  }
+  if (int rc = flush()) return rc;
+  // final linear: 2 jobs per output row group via a second launch with row-strided destinations
+  PackArgs b;
+  int nb = 0;
+  for (int o = 0; o < 16; ++o) {
+    const bool live = o < d->out_dim;
+    PackJob j1 = {params + d->off_wf + (size_t)(live ? o : 0) * (H + L), d->pk_wf + (long)o * (HP + LP), live ? 1 : 0, H,
+                  H + L, 1, HP, 0};
+    PackJob j2 = {params + d->off_wf + (size_t)(live ? o : 0) * (H + L) + H, d->pk_wf + (long)o * (HP + LP) + HP,
+                  live ? 1 : 0, L, H + L, 1, LP, 0};
+    b.job[nb++] = j1;
+    b.job[nb++] = j2;
+  }
+  b.njobs = nb;
+  b.packed = packed;
+  dim3 grid2(1, nb);
+  hipLaunchKernelGGL((k_pack<T>), grid2, dim3(256), 0, s, b);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_siren_pack(const cinema_siren_desc *d, const float *params, void *packed, void *stream) {
+  CINEMA_REQUIRE(d && params && packed, "cinema_siren_pack: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16 ? pack_impl<bf16_t>(d, params, packed, s) : pack_impl<float>(d, params, packed, s);
+}
+
+template <typename T, bool MOD, bool SMALLK>
+static int launch_fwd(const FwdArgs &a, int grid, hipStream_t s) {
+  constexpr int smem = Engine<T>::NT_SMEM;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (int rc = set_smem_attr<T>((const void *)k_layer_fwd<T, MOD, SMALLK>, smem)) return rc;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_layer_fwd<T, MOD, SMALLK>), dim3(grid), dim3(WG_THREADS), smem, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int forward_impl(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
+                        const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s) {
+  const int H = d->hidden, HP = d->HP, LP = d->LP;
+  const T *pk = (const T *)packed;
+  T *sv = (T *)saved;
+  const size_t slot = (size_t)Npad * HP;
+  const int tiles_f = (HP + 127) / 128;
+  const int grid = tiles_f * (int)(Npad / 128);
+  for (int i = 0; i < d->n_layers; ++i) {
+    const bool mod = (d->modulated_mask >> i) & 1u;
+    FwdArgs a = {};
+    a.bias = params + d->off_b[i];
+    a.H = H; a.HP = HP; a.ldo = HP; a.tiles_f = tiles_f;
+    a.omega = i == 0 ? d->omega_first : d->omega_hidden;
+    a.Y = sv + slot * d->sv_y[i];
+    a.C = sv + slot * d->sv_c[i];
+    a.rowsW = HP;
+    if (mod) {
+      a.LAT = lat; a.LP = LP;
+      a.Wls = pk + d->pk_wls[i];
+      a.Wlt = pk + d->pk_wlt[i];
+      a.bias_l = params + d->off_bl[i];
+      a.Z = sv + slot * d->sv_z[i];
+      a.S = sv + slot * d->sv_s[i];
+    }
+    int rc;
+    if (i == 0) {
+      a.Xs = coords_t; a.ldxs = d->in_dim; a.ks = d->in_dim;
+      a.Ws = params + d->off_w[0]; a.ws_sf = d->in_dim; a.ws_sk = 1;
+      rc = mod ? launch_fwd<T, true, true>(a, grid, s) : launch_fwd<T, false, true>(a, grid, s);
+    } else {
+      a.X = sv + slot * d->sv_y[i - 1]; a.ldx = HP;
+      a.W = pk + d->pk_w[i]; a.K = HP;
+      rc = mod ? launch_fwd<T, true, false>(a, grid, s) : launch_fwd<T, false, false>(a, grid, s);
+    }
+    if (rc) return rc;
+  }
+  // final linear
+  FinalFwdArgs f = {};
+  f.X = sv + slot * d->sv_y[d->n_layers - 1]; f.ldx = HP; f.HP = HP;
+  f.LAT = lat; f.LP = LP;
+  f.Wf = pk + d->pk_wf;
+  f.bias = params + d->off_bf;
+  f.out_dim = d->out_dim; f.out = out; f.Npad = (int)Npad;
+  const int smem = 16 * ((HP + LP) * (int)sizeof(T) + FinalK<T>::PADB);
+  static bool attr_done = false;
+  if (!attr_done) {
+    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_final_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024 - 1024));
+    attr_done = true;
+  }
+  CINEMA_REQUIRE(smem <= 159 * 1024, "final_linear too wide for LDS staging: hidden %d + lat %d", H, d->lat);
+  const int fgrid = (int)std::min<int64_t>(Npad / 64, 1024);
+  hipLaunchKernelGGL((k_final_fwd<T>), dim3(fgrid), dim3(WG_THREADS), smem, s, f);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  (void)N;
+  return 0;
+}
+
+extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *params, const void *packed,
+                                    const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
+                                    float *out, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && saved && out, "cinema_siren_forward: null argument");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0, "cinema_siren_forward: need 1 <= N <= Npad, Npad %% 128 == 0 (N=%ld Npad=%ld)",
+                 (long)N, (long)Npad);
+  CINEMA_REQUIRE(Npad / 128 * ((d->HP + 127) / 128) < (1 << 30), "grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16
+             ? forward_impl<bf16_t>(d, params, packed, coords_t, lat, N, Npad, saved, out, s)
+             : forward_impl<float>(d, params, packed, coords_t, lat, N, Npad, saved, out, s);
+}
+
+template <typename T, bool MOD, bool SMALLK, bool FIRST>
+static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
+  constexpr int smem = Engine<T>::NT_SMEM;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (int rc = set_smem_attr<T>((const void *)k_layer_bwd<T, MOD, SMALLK, FIRST>, smem)) return rc;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_layer_bwd<T, MOD, SMALLK, FIRST>), dim3(grid), dim3(WG_THREADS), smem, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int backward_impl(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
+                         const void *lat, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
+                         float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s) {
+  const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP, nl = d->n_layers;
+  const bool wgrads = !(flags & CINEMA_BWD_SKIP_WEIGHT_GRADS);
+  const T *pk = (const T *)packed;
+  const T *sv = (const T *)saved;
+  T *gb = (T *)gbuf;
+  const size_t slot = (size_t)Npad * HP;
+  const int tiles_f = (HP + 127) / 128;
+  const int grid = tiles_f * (int)(Npad / 128);
+  if (wgrads) CINEMA_CHECK_HIP(hipMemsetAsync(gp, 0, sizeof(float) * (size_t)d->n_params, s));
+  CINEMA_CHECK_HIP(hipMemsetAsync(dcoords, 0, sizeof(float) * (size_t)Npad * d->in_dim, s));
+
+  // ---- chain ----
+  for (int i = nl - 1; i >= 0; --i) {
+    const bool mod = (d->modulated_mask >> i) & 1u;
+    const bool top = i == nl - 1, first = i == 0;
+    BwdArgs a = {};
+    a.C = sv + slot * d->sv_c[i];
+    a.ldo = HP; a.HP = HP; a.H = H; a.tiles_f = tiles_f;
+    a.omega = first ? d->omega_first : d->omega_hidden;
+    a.DZ = gb + slot * d->gb_z[i];
+    if (mod) {
+      a.Z = sv + slot * d->sv_z[i];
+      a.S = sv + slot * d->sv_s[i];
+      a.DS = gb + slot * d->gb_s[i];
+      a.DT = gb + slot * d->gb_t[i];
+    }
+    if (wgrads) {
+      a.db = gp + d->off_b[i];
+      a.dbl = mod ? gp + d->off_bl[i] : nullptr;
+    }
+    if (top) {
+      a.Xs = dout; a.ldxs = d->out_dim; a.ks = d->out_dim;
+      a.Ws = params + d->off_wf; a.ws_sf = 1; a.ws_sk = H + L;   // element (f, o) = Wf[o][f]
+    } else {
+      a.G = gb + slot * d->gb_z[i + 1]; a.ldg = HP;
+      a.WT = pk + d->pk_wt[i + 1]; a.Kred = HP; a.rowsWT = HP;
+    }
+    if (first) {
+      a.coords = coords_t; a.in_dim = d->in_dim;
+      a.W0 = params + d->off_w[0];
+      a.dW0 = wgrads ? gp + d->off_w[0] : nullptr;
+      a.dcoords = dcoords;
+      if (!wgrads) { a.db = nullptr; }
+    }
+    int rc;
+    // FIRST kernels need db != NULL to enter the reduction block that also produces dW0; with frozen weights
+    // the whole block is skipped (dcoords is accumulated in the per-sample loop above it).
+    if (top && first) rc = mod ? launch_bwd<T, true, true, true>(a, grid, s) : launch_bwd<T, false, true, true>(a, grid, s);
+    else if (top) rc = mod ? launch_bwd<T, true, true, false>(a, grid, s) : launch_bwd<T, false, true, false>(a, grid, s);
+    else if (first) rc = mod ? launch_bwd<T, true, false, true>(a, grid, s) : launch_bwd<T, false, false, true>(a, grid, s);
+    else rc = mod ? launch_bwd<T, true, false, false>(a, grid, s) : launch_bwd<T, false, false, false>(a, grid, s);
+    if (rc) return rc;
+  }
+
+  // ---- d lat ----
+  {
+    DlatArgs a = {};
+    int ns = 0;
+    for (int i = 0; i < nl; ++i)
+      if ((d->modulated_mask >> i) & 1u) {
+        a.seg[ns].Wt = pk + d->pk_wlsT[i]; a.seg[ns].G = gb + slot * d->gb_s[i]; a.seg[ns].K = HP; ++ns;
+        a.seg[ns].Wt = pk + d->pk_wltT[i]; a.seg[ns].G = gb + slot * d->gb_t[i]; a.seg[ns].K = HP; ++ns;
+      }
+    a.nseg = ns;
+    a.Xs = dout; a.ldxs = d->out_dim; a.ks = d->out_dim;
+    a.Ws = params + d->off_wf + H; a.ws_sf = 1; a.ws_sk = H + L;
+    a.lat = L; a.LP = LP; a.ldg = HP; a.out = dlat;
+    a.tiles_f = (LP + 127) / 128;
+    const int g2 = a.tiles_f * (int)(Npad / 128);
+    constexpr int smem = Engine<T>::NT_SMEM;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (int rc = set_smem_attr<T>((const void *)k_dlat<T>, smem)) return rc;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  if (!wgrads) return 0;
+
+  // ---- weight gradients: one grouped launch ----
+  {
+    DwArgs a = {};
+    int np = 0, tiles = 0;
+    auto add = [&](const void *P, const void *Q, float *out, int ldp, int ldq, int ldo, int M, int K) {
+      DwProb p = {P, Q, out, ldp, ldq, ldo, M, K, (K + 127) / 128};
+      a.p[np] = p;
+      a.tile_start[np] = tiles;
+      tiles += ((M + 127) / 128) * p.tk;
+      ++np;
+    };
+    for (int i = nl - 1; i >= 0; --i) {
+      if (i > 0) add(gb + slot * d->gb_z[i], sv + slot * d->sv_y[i - 1], gp + d->off_w[i], HP, HP, H, H, H);
+      if ((d->modulated_mask >> i) & 1u) {
+        add(gb + slot * d->gb_s[i], lat, gp + d->off_wl[i], HP, LP, L, H, L);
+        add(gb + slot * d->gb_t[i], lat, gp + d->off_wl[i] + (size_t)H * L, HP, LP, L, H, L);
+      }
+    }
+    if (np > 0) {
+      a.tile_start[np] = tiles;
+      a.nprob = np;
+      a.Npad = (int)Npad;
+      const int ntile = (int)(Npad / Engine<T>::BN);
+      int splitk = std::max(1, 512 / std::max(tiles, 1));
+      splitk = std::min(splitk, std::max(1, ntile / 4));
+      a.splitk = splitk;
+      constexpr int smem = Engine<T>::TN_SMEM;
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (int rc = set_smem_attr<T>((const void *)k_dw_grouped<T>, smem)) return rc;
+        attr_done = true;
+      }
+      hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * splitk), dim3(WG_THREADS), smem, s, a);
+      CINEMA_CHECK_HIP(hipGetLastError());
+    }
+  }
+  // ---- final_linear weight / bias gradients ----
+  {
+    FinalBwdArgs a = {};
+    a.X = sv + slot * d->sv_y[nl - 1]; a.ldx = HP; a.H = H;
+    a.LAT = lat; a.LP = LP; a.lat = L;
+    a.dout = dout; a.out_dim = d->out_dim;
+    a.dWf = gp + d->off_wf; a.dbf = gp + d->off_bf; a.Npad = (int)Npad;
+    const int grid_f = (int)std::min<int64_t>(Npad / 32, 256);
+    hipLaunchKernelGGL((k_final_bwd_dw<T>), dim3(grid_f), dim3(WG_THREADS), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  (void)N;
+  return 0;
+}
+
+extern "C" int cinema_siren_backward(const cinema_siren_desc *d, const float *params, const void *packed,
+                                     const float *coords_t, const void *lat, const void *saved, const float *dout,
+                                     int64_t N, int64_t Npad, void *gbuf, float *grad_params, float *dlat,
+                                     float *dcoords, int32_t flags, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && saved && dout && gbuf && dlat && dcoords,
+                 "cinema_siren_backward: null argument");
+  CINEMA_REQUIRE((flags & CINEMA_BWD_SKIP_WEIGHT_GRADS) || grad_params, "cinema_siren_backward: grad_params is null");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0, "cinema_siren_backward: need 1 <= N <= Npad, Npad %% 128 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16
+             ? backward_impl<bf16_t>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
+                                     dcoords, flags, s)
+             : backward_impl<float>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
+                                    dcoords, flags, s);
+}

@@ -1,0 +1,491 @@
+// K1: per-subject affine registration + trilinear interpolation of the spatial latent grid.
+// Reference arithmetic: utils.py:126-166 (embed2affine / euler2rot),
+// models/inr_decoder.py:64-71 (transform), :33 ([idcs_df] gather), :73-85 (grid_sample 5-D,
+// bilinear, align_corners=True, padding_mode='border').
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+struct M3 {
+  float m[3][3];
+};
+__device__ __forceinline__ M3 m3_identity() {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = i == j ? 1.f : 0.f;
+  return r;
+}
+__device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+  return r;
+}
+__device__ __forceinline__ M3 m3_t(const M3 &a) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+  return r;
+}
+__device__ __forceinline__ float m3_dot(const M3 &a, const M3 &b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s += a.m[i][j] * b.m[i][j];
+  return s;
+}
+__device__ __forceinline__ M3 rot_z(float c, float s) {
+  M3 r = m3_identity();
+  r.m[0][0] = c; r.m[0][1] = -s; r.m[1][0] = s; r.m[1][1] = c;
+  return r;
+}
+__device__ __forceinline__ M3 rot_x(float c, float s) {
+  M3 r = m3_identity();
+  r.m[1][1] = c; r.m[1][2] = -s; r.m[2][1] = s; r.m[2][2] = c;
+  return r;
+}
+// derivative matrices d/da of rot_z / rot_x
+__device__ __forceinline__ M3 drot_z(float c, float s) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = 0.f;
+  r.m[0][0] = -s; r.m[0][1] = -c; r.m[1][0] = c; r.m[1][1] = -s;
+  return r;
+}
+__device__ __forceinline__ M3 drot_x(float c, float s) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = 0.f;
+  r.m[1][1] = -s; r.m[1][2] = -c; r.m[2][1] = c; r.m[2][2] = -s;
+  return r;
+}
+__device__ __forceinline__ void shear_mats(const float *e, M3 &sx, M3 &sy, M3 &sz) {
+  const float hx = e[9], hy = e[10], hz = e[11];
+  sx = m3_identity(); sy = m3_identity(); sz = m3_identity();
+  sx.m[0][1] = hy; sx.m[0][2] = hz;
+  sy.m[1][0] = hx; sy.m[1][2] = hz;
+  sz.m[2][0] = hx; sz.m[2][1] = hy;
+}
+
+// A = Rz(e0) Rx(e1) Rz(e2) [diag(1+e6..8)] [Sx Sy Sz],  t = e3..5        (utils.py:126-166)
+__device__ __forceinline__ M3 affine_from_embed(const float *e, int dim) {
+  float s1, c1, s2, c2, s3, c3;
+  sincosf(e[0], &s1, &c1);
+  sincosf(e[1], &s2, &c2);
+  sincosf(e[2], &s3, &c3);
+  M3 A = m3_mul(m3_mul(rot_z(c1, s1), rot_x(c2, s2)), rot_z(c3, s3));
+  if (dim >= 9) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A.m[i][j] *= 1.f + e[6 + j];
+  }
+  if (dim == 12) {
+    M3 sx, sy, sz;
+    shear_mats(e, sx, sy, sz);
+    A = m3_mul(m3_mul(m3_mul(A, sx), sy), sz);
+  }
+  return A;
+}
+
+__global__ void k_affine_from_embed(const float *embed, long rows, int dim, float *affine) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float e[12];
+  for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[r * dim + k] : 0.f;
+  const M3 A = affine_from_embed(e, dim);
+  float *o = affine + r * 12;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[3 * i + j] = A.m[i][j];
+  o[9] = e[3]; o[10] = e[4]; o[11] = e[5];
+}
+
+// d embed from d coords_t:  coords_t = A c + t
+__global__ void k_affine_bwd(const float *coords, const int32_t *idx, const float *embed, int dim, int per_sample,
+                             const float *dct, long N, long S, float *dembed) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  long row = n;
+  if (!per_sample) {
+    long s = idx[n];
+    row = s < 0 ? 0 : (s >= S ? S - 1 : s);
+  }
+  float e[12];
+  for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[row * dim + k] : 0.f;
+  const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
+  const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
+  M3 G;  // dL/dA
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G.m[i][j] = d[i] * c[j];
+  float s1, c1, s2, c2, s3, c3;
+  sincosf(e[0], &s1, &c1);
+  sincosf(e[1], &s2, &c2);
+  sincosf(e[2], &s3, &c3);
+  const M3 Rz1 = rot_z(c1, s1), Rx2 = rot_x(c2, s2), Rz3 = rot_z(c3, s3);
+  const M3 R = m3_mul(m3_mul(Rz1, Rx2), Rz3);
+  M3 D = m3_identity(), Sh = m3_identity(), sx = m3_identity(), sy = m3_identity(), sz = m3_identity();
+  if (dim >= 9) { D.m[0][0] = 1.f + e[6]; D.m[1][1] = 1.f + e[7]; D.m[2][2] = 1.f + e[8]; }
+  if (dim == 12) { shear_mats(e, sx, sy, sz); Sh = m3_mul(m3_mul(sx, sy), sz); }
+  float g[12];
+  // rotation angles: <G (D Sh)^T, dR/dtheta>
+  const M3 GR = m3_mul(G, m3_t(m3_mul(D, Sh)));
+  g[0] = m3_dot(GR, m3_mul(m3_mul(drot_z(c1, s1), Rx2), Rz3));
+  g[1] = m3_dot(GR, m3_mul(m3_mul(Rz1, drot_x(c2, s2)), Rz3));
+  g[2] = m3_dot(GR, m3_mul(m3_mul(Rz1, Rx2), drot_z(c3, s3)));
+  g[3] = d[0]; g[4] = d[1]; g[5] = d[2];
+  if (dim >= 9) {
+    const M3 GD = m3_mul(m3_mul(m3_t(R), G), m3_t(Sh));
+    g[6] = GD.m[0][0]; g[7] = GD.m[1][1]; g[8] = GD.m[2][2];
+  }
+  if (dim == 12) {
+    const M3 GS = m3_mul(m3_t(m3_mul(R, D)), G);                 // dL/dSh
+    const M3 gsx = m3_mul(GS, m3_t(m3_mul(sy, sz)));
+    const M3 gsy = m3_mul(m3_mul(m3_t(sx), GS), m3_t(sz));
+    const M3 gsz = m3_mul(m3_t(m3_mul(sx, sy)), GS);
+    g[9] = gsy.m[1][0] + gsz.m[2][0];
+    g[10] = gsx.m[0][1] + gsz.m[2][1];
+    g[11] = gsx.m[0][2] + gsy.m[1][2];
+  }
+  if (per_sample) {
+    for (int k = 0; k < dim; ++k) dembed[n * dim + k] = g[k];
+  } else {
+    for (int k = 0; k < dim; ++k) atomicAdd(dembed + row * dim + k, g[k]);
+  }
+}
+
+__global__ void k_node_major(const float *lat, long S, int C, int G, float *shadow) {
+  // (S, C, G) -> (S, G, C); one block per (subject, 32x32 tile) through LDS
+  __shared__ float tile[32][33];
+  const long s = blockIdx.z;
+  const int c0 = blockIdx.y * 32, g0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, g = g0 + tx;
+    tile[r][tx] = (c < C && g < G) ? lat[(s * C + c) * G + g] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int g = g0 + r, c = c0 + tx;
+    if (g < G && c < C) shadow[(s * G + g) * C + c] = tile[tx][r];
+  }
+}
+
+struct Axis {
+  int i0, i1;
+  float w0, w1;
+  float dmul;   // d u / d x if the clip is inactive, else 0
+};
+__device__ __forceinline__ Axis axis_nodes(float x, int size) {
+  Axis a;
+  float u = (x + 1.f) * 0.5f * (float)(size - 1);
+  const float hi = (float)(size - 1);
+  a.dmul = (u > 0.f && u < hi) ? 0.5f * hi : 0.f;
+  u = fminf(fmaxf(u, 0.f), hi);
+  const float f = floorf(u);
+  a.i0 = (int)f;
+  a.w1 = u - f;
+  a.w0 = 1.f - a.w1;
+  a.i1 = a.i0 + 1;
+  if (a.i1 > size - 1) { a.i1 = a.i0; a.w1 = 0.f; }
+  return a;
+}
+
+struct TriArgs {
+  const float *coords; const int32_t *idx; const float *affine; int affine_per_sample;
+  const float *shadow; const float *cond;
+  long N, Npad, S; int C, lx, ly, lz, cond_dims, LP;
+  float *coords_t; void *lat_out;
+};
+
+__device__ __forceinline__ void corner_setup(const Axis &ax, const Axis &ay, const Axis &az, int ly, int lz,
+                                             int (&node)[8], float (&w)[8]) {
+  int q = 0;
+#pragma unroll
+  for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+    for (int by = 0; by < 2; ++by)
+#pragma unroll
+      for (int bz = 0; bz < 2; ++bz) {
+        const int ix = bx ? ax.i1 : ax.i0, iy = by ? ay.i1 : ay.i0, iz = bz ? az.i1 : az.i0;
+        node[q] = (ix * ly + iy) * lz + iz;
+        w[q] = (bx ? ax.w1 : ax.w0) * (by ? ay.w1 : ay.w0) * (bz ? az.w1 : az.w0);
+        ++q;
+      }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_trilerp_fwd(TriArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T *out = (T *)a.lat_out;
+  const int G = a.lx * a.ly * a.lz;
+  for (long n = (long)blockIdx.x * 4 + wave; n < a.Npad; n += (long)gridDim.x * 4) {
+    T *orow = out + n * a.LP;
+    if (n >= a.N) {
+      if (lane < 3) a.coords_t[n * 3 + lane] = 0.f;
+      for (int j = lane; j < a.LP; j += 64) orow[j] = (T)0.f;
+      continue;
+    }
+    const float cx = a.coords[n * 3], cy = a.coords[n * 3 + 1], cz = a.coords[n * 3 + 2];
+    long s = a.idx[n];
+    s = s < 0 ? 0 : (s >= a.S ? a.S - 1 : s);
+    float t0 = cx, t1 = cy, t2 = cz;
+    if (a.affine != nullptr) {
+      const float *A = a.affine + (a.affine_per_sample ? n : s) * 12;
+      t0 = A[0] * cx + A[1] * cy + A[2] * cz + A[9];
+      t1 = A[3] * cx + A[4] * cy + A[5] * cz + A[10];
+      t2 = A[6] * cx + A[7] * cy + A[8] * cz + A[11];
+    }
+    if (lane == 0) { a.coords_t[n * 3] = t0; a.coords_t[n * 3 + 1] = t1; a.coords_t[n * 3 + 2] = t2; }
+    // coordinate column 0 walks the LAST grid axis (lz), column 1 ly, column 2 lx
+    const Axis az = axis_nodes(t0, a.lz), ay = axis_nodes(t1, a.ly), ax = axis_nodes(t2, a.lx);
+    int node[8]; float w[8];
+    corner_setup(ax, ay, az, a.ly, a.lz, node, w);
+    const float *base = a.shadow + s * (long)G * a.C;
+    for (int c = lane; c < a.C; c += 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += w[q] * base[(long)node[q] * a.C + c];
+      orow[c] = (T)v;
+    }
+    for (int j = lane; j < a.cond_dims; j += 64) orow[a.C + j] = (T)a.cond[n * a.cond_dims + j];
+    for (int j = a.C + a.cond_dims + lane; j < a.LP; j += 64) orow[j] = (T)0.f;
+  }
+}
+
+// gradient w.r.t. the registered coordinates through the interpolation + d cond
+struct TriBwdArgs {
+  const int32_t *idx; const float *shadow; const float *coords_t; const float *dlat;
+  long N, S; int C, lx, ly, lz, cond_dims, LP;
+  float *dcoords_t; float *dcond;
+};
+
+__global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = a.lx * a.ly * a.lz;
+  for (long n = (long)blockIdx.x * 4 + wave; n < a.N; n += (long)gridDim.x * 4) {
+    const float t0 = a.coords_t[n * 3], t1 = a.coords_t[n * 3 + 1], t2 = a.coords_t[n * 3 + 2];
+    long s = a.idx[n];
+    s = s < 0 ? 0 : (s >= a.S ? a.S - 1 : s);
+    const Axis az = axis_nodes(t0, a.lz), ay = axis_nodes(t1, a.ly), ax = axis_nodes(t2, a.lx);
+    const float *base = a.shadow + s * (long)G * a.C;
+    const float *grow = a.dlat + n * a.LP;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (ax.dmul != 0.f || ay.dmul != 0.f || az.dmul != 0.f) {
+      for (int c = lane; c < a.C; c += 64) {
+        const float go = grow[c];
+        float v[8];
+        int q = 0;
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+          for (int by = 0; by < 2; ++by)
+#pragma unroll
+            for (int bz = 0; bz < 2; ++bz) {
+              const int ix = bx ? ax.i1 : ax.i0, iy = by ? ay.i1 : ay.i0, iz = bz ? az.i1 : az.i0;
+              v[q++] = base[(long)((ix * a.ly + iy) * a.lz + iz) * a.C + c];
+            }
+        // v index = bx*4 + by*2 + bz
+        const float dx = (ay.w0 * (az.w0 * (v[4] - v[0]) + az.w1 * (v[5] - v[1])) +
+                          ay.w1 * (az.w0 * (v[6] - v[2]) + az.w1 * (v[7] - v[3])));
+        const float dy = (ax.w0 * (az.w0 * (v[2] - v[0]) + az.w1 * (v[3] - v[1])) +
+                          ax.w1 * (az.w0 * (v[6] - v[4]) + az.w1 * (v[7] - v[5])));
+        const float dz = (ax.w0 * (ay.w0 * (v[1] - v[0]) + ay.w1 * (v[3] - v[2])) +
+                          ax.w1 * (ay.w0 * (v[5] - v[4]) + ay.w1 * (v[7] - v[6])));
+        gx += go * dx; gy += go * dy; gz += go * dz;
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        gx += __shfl_xor(gx, m, 64);
+        gy += __shfl_xor(gy, m, 64);
+        gz += __shfl_xor(gz, m, 64);
+      }
+      if (lane == 0) {
+        a.dcoords_t[n * 3] += gz * az.dmul;       // column 0 <-> lz axis
+        a.dcoords_t[n * 3 + 1] += gy * ay.dmul;
+        a.dcoords_t[n * 3 + 2] += gx * ax.dmul;
+      }
+    }
+    if (a.dcond != nullptr)
+      for (int j = lane; j < a.cond_dims; j += 64) a.dcond[n * a.cond_dims + j] = grow[a.C + j];
+  }
+}
+
+// ---- grouping of the samples by subject (counting sort) ----
+__global__ void k_hist(const int32_t *idx, long N, long S, int32_t *counts) {
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    long s = idx[n];
+    s = s < 0 ? 0 : (s >= S ? S - 1 : s);
+    atomicAdd(counts + s, 1);
+  }
+}
+__global__ void k_scan(int32_t *counts, long S, int32_t *offsets) {
+  // single block; serial over chunks of blockDim with a running carry (S is small: #subjects)
+  __shared__ int32_t buf[1024];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (long b = 0; b < S; b += blockDim.x) {
+    const long s = b + threadIdx.x;
+    const int32_t v = s < S ? counts[s] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < (int)blockDim.x; d <<= 1) {
+      const int32_t t = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (s < S) {
+      offsets[s] = carry + buf[threadIdx.x] - v;
+      counts[s] = 0;   // becomes the fill cursor
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry += buf[blockDim.x - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[S] = carry;
+}
+__global__ void k_fill(const int32_t *idx, long N, long S, const int32_t *offsets, int32_t *cursor, int32_t *perm) {
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    long s = idx[n];
+    s = s < 0 ? 0 : (s >= S ? S - 1 : s);
+    const int pos = offsets[s] + atomicAdd(cursor + s, 1);
+    perm[pos] = (int32_t)n;
+  }
+}
+
+// d latents: one workgroup per (subject, 64-channel slice); the subject's samples are summed in LDS
+struct LatRedArgs {
+  const int32_t *offsets; const int32_t *perm; const float *coords_t; const float *dlat;
+  int C, lx, ly, lz, LP; float *dlatents;
+};
+__global__ __launch_bounds__(256) void k_lat_reduce(LatRedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *acc = reinterpret_cast<float *>(smem_raw);   // [4][G][64]
+  const int G = a.lx * a.ly * a.lz;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long s = blockIdx.x;
+  const int c0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 4 * G * 64; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  float *mine = acc + wave * G * 64;
+  const int beg = a.offsets[s], end = a.offsets[s + 1];
+  const int c = c0 + lane;
+  for (int p = beg + wave; p < end; p += 4) {
+    const long n = a.perm[p];
+    const Axis az = axis_nodes(a.coords_t[n * 3], a.lz), ay = axis_nodes(a.coords_t[n * 3 + 1], a.ly),
+               ax = axis_nodes(a.coords_t[n * 3 + 2], a.lx);
+    int node[8]; float w[8];
+    corner_setup(ax, ay, az, a.ly, a.lz, node, w);
+    const float v = c < a.C ? a.dlat[n * a.LP + c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mine[node[q] * 64 + lane] += w[q] * v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * G; e += 256) {
+    const int cc = e / G, nd = e - cc * G;
+    if (c0 + cc < a.C) {
+      const int o = nd * 64 + cc;
+      a.dlatents[(s * a.C + c0 + cc) * G + nd] = acc[o] + acc[G * 64 + o] + acc[2 * G * 64 + o] + acc[3 * G * 64 + o];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cinema_affine_from_embedding(const float *embed, int64_t rows, int32_t tf_dim, float *affine, void *stream) {
+  CINEMA_REQUIRE(embed && affine, "cinema_affine_from_embedding: null argument");
+  CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_affine_from_embed, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, embed,
+                     (long)rows, tf_dim, affine);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_latent_to_node_major(const float *latents, int64_t S, int32_t C, int32_t G, float *shadow, void *stream) {
+  CINEMA_REQUIRE(latents && shadow && S >= 1 && C >= 1 && G >= 1, "cinema_latent_to_node_major: bad argument");
+  CINEMA_REQUIRE(S <= 65535, "too many subjects per rank (%ld > 65535)", (long)S);
+  dim3 grid((G + 31) / 32, (C + 31) / 32, (unsigned)S);
+  hipLaunchKernelGGL(k_node_major, grid, dim3(256), 0, (hipStream_t)stream, latents, (long)S, C, G, shadow);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx, const float *affine,
+                                         int32_t affine_per_sample, const float *shadow, const float *cond, int64_t N,
+                                         int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                                         int32_t cond_dims, int32_t precision, float *coords_t, void *lat_out, int32_t LP,
+                                         void *stream) {
+  CINEMA_REQUIRE(coords && idx && shadow && coords_t && lat_out, "cinema_affine_trilerp_fwd: null argument");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_affine_trilerp_fwd: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
+  CINEMA_REQUIRE(lx >= 1 && ly >= 1 && lz >= 1 && C >= 1, "bad latent grid %d x %d x %d x %d", C, lx, ly, lz);
+  CINEMA_REQUIRE(cond_dims == 0 || cond != nullptr, "cond_dims %d but cond is null", cond_dims);
+  CINEMA_REQUIRE(LP >= C + cond_dims, "LP %d < C + cond_dims = %d", LP, C + cond_dims);
+  TriArgs a = {coords, idx, affine, affine_per_sample, shadow, cond, (long)N, (long)Npad, (long)S, C, lx, ly, lz, cond_dims, LP,
+               coords_t, lat_out};
+  const unsigned grid = (unsigned)std::min<long>((Npad + 3) / 4, 8192);
+  if (precision == CINEMA_PREC_BF16) hipLaunchKernelGGL(k_trilerp_fwd<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_trilerp_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                         int32_t embed_per_sample, const float *affine, const float *shadow,
+                                         const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
+                                         int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                                         float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream) {
+  (void)affine; (void)Npad;
+  CINEMA_REQUIRE(coords && idx && coords_t && dcoords_t, "cinema_affine_trilerp_bwd: null argument");
+  CINEMA_REQUIRE(dlat == nullptr || (shadow && work), "cinema_affine_trilerp_bwd: dlat given without shadow/work");
+  CINEMA_REQUIRE(dlatents == nullptr || dlat != nullptr, "cinema_affine_trilerp_bwd: dlatents requested without dlat");
+  CINEMA_REQUIRE(N >= 1 && S >= 1, "cinema_affine_trilerp_bwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int G = lx * ly * lz;
+  if (dlat != nullptr) {
+    TriBwdArgs a = {idx, shadow, coords_t, dlat, (long)N, (long)S, C, lx, ly, lz, cond_dims, LP, dcoords_t, dcond};
+    const unsigned grid = (unsigned)std::min<long>((N + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_trilerp_bwd_coord, dim3(grid), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  if (dembed != nullptr) {
+    CINEMA_REQUIRE(embed != nullptr, "dembed requested but embed is null");
+    CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+    hipLaunchKernelGGL(k_affine_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, idx, embed, tf_dim,
+                       embed_per_sample, dcoords_t, (long)N, (long)S, dembed);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  if (dlatents != nullptr) {
+    int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
+    CINEMA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)S, s));
+    const unsigned g1 = (unsigned)std::min<long>((N + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_hist, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, counts);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, (long)S, offsets);
+    hipLaunchKernelGGL(k_fill, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, offsets, counts, perm);
+    CINEMA_CHECK_HIP(hipGetLastError());
+    const int smem = 4 * G * 64 * (int)sizeof(float);
+    CINEMA_REQUIRE(smem <= 64 * 1024, "latent grid of %d nodes too large for the LDS reduction (max 64)", G);
+    CINEMA_REQUIRE(S <= 0x7fffffff && (C + 63) / 64 <= 65535, "grid too large");
+    LatRedArgs a = {offsets, perm, coords_t, dlat, C, lx, ly, lz, LP, dlatents};
+    hipLaunchKernelGGL(k_lat_reduce, dim3((unsigned)S, (C + 63) / 64), dim3(256), smem, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}

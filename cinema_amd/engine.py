@@ -1,0 +1,245 @@
+"""Host-side driver of the HIP hot path: owns the flat parameter buffer, the packed bf16/f32
+weight copies and the per-batch workspaces, and sequences the C-ABI calls.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic step of the path runs in
+libcinema_hip.so.  There is no eager fallback: constructing an engine without the library or
+without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import SirenDesc, check, ptr
+
+ROW_ALIGN = 128
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def default_precision(amp: Optional[bool] = None) -> int:
+    """bf16 MFMA unless CINEMA_PRECISION=fp32 or the reference's `amp: False` is configured."""
+    env = os.environ.get("CINEMA_PRECISION", "").lower()
+    if env in ("fp32", "f32", "float32"):
+        return _lib.PREC_F32
+    if env in ("bf16", "bfloat16"):
+        return _lib.PREC_BF16
+    if amp is not None and not amp:
+        return _lib.PREC_F32
+    return _lib.PREC_BF16
+
+
+def make_desc(in_dim: int, lat: int, out_dim: int, hidden: int, n_sine_layers: int, modulated_layers: Sequence[int],
+              omega_first: float, omega_hidden: float, precision: int) -> SirenDesc:
+    d = SirenDesc()
+    d.n_layers, d.in_dim, d.hidden, d.lat, d.out_dim, d.precision = n_sine_layers, in_dim, hidden, lat, out_dim, precision
+    mask = 0
+    for i in modulated_layers:
+        if 0 <= i < n_sine_layers:
+            mask |= 1 << i
+    d.modulated_mask = mask
+    d.omega_first, d.omega_hidden = float(omega_first), float(omega_hidden)
+    check(_lib.load().cinema_siren_plan(C.byref(d)), "cinema_siren_plan")
+    return d
+
+
+def param_layout(d: SirenDesc) -> List[Tuple[str, int, Tuple[int, ...]]]:
+    """(state_dict key, offset in floats, shape) in the flat-buffer order (= the reference's
+    state_dict order: final_linear first, models/siren.py:50-57)."""
+    H, L = d.hidden, d.lat
+    out = [("final_linear.weight", d.off_wf, (d.out_dim, H + L)), ("final_linear.bias", d.off_bf, (d.out_dim,))]
+    for i in range(d.n_layers):
+        fan_in = d.in_dim if i == 0 else H
+        out.append((f"net.{i}.linear.weight", d.off_w[i], (H, fan_in)))
+        out.append((f"net.{i}.linear.bias", d.off_b[i], (H,)))
+        if (d.modulated_mask >> i) & 1:
+            out.append((f"net.{i}.linear_lats.weight", d.off_wl[i], (2 * H, L)))
+            out.append((f"net.{i}.linear_lats.bias", d.off_bl[i], (2 * H,)))
+    return out
+
+
+class Workspace:
+    """Device buffers for one batch size; reused across steps (the library allocates nothing)."""
+
+    def __init__(self, d: SirenDesc, n_rows: int, device, in_dim: int):
+        self.npad_cap = round_up(max(n_rows, 1), ROW_ALIGN)
+        dt = torch.bfloat16 if d.precision == _lib.PREC_BF16 else torch.float32
+        n = self.npad_cap
+        self.coords_t = torch.empty(n, in_dim, device=device, dtype=torch.float32)
+        self.lat = torch.empty(n, d.LP, device=device, dtype=dt)
+        self.saved = torch.empty(d.n_saved, n, d.HP, device=device, dtype=dt)
+        self.out = torch.empty(n, d.out_dim, device=device, dtype=torch.float32)
+        self.gbuf = None       # backward-only buffers are allocated on first use
+        self.dlat = None
+        self.dcoords = None
+        self.dout = None
+        self._d = d
+        self._dt = dt
+        self._device = device
+        self._in_dim = in_dim
+
+    def ensure_backward(self):
+        if self.gbuf is None:
+            d, n = self._d, self.npad_cap
+            self.gbuf = torch.empty(d.n_gbuf, n, d.HP, device=self._device, dtype=self._dt)
+            self.dlat = torch.empty(n, d.LP, device=self._device, dtype=torch.float32)
+            self.dcoords = torch.empty(n, self._in_dim, device=self._device, dtype=torch.float32)
+            self.dout = torch.zeros(n, d.out_dim, device=self._device, dtype=torch.float32)
+
+
+class SirenEngine:
+    """Flat parameters + packed copies + workspaces for one Siren stack on one device."""
+
+    def __init__(self, desc: SirenDesc, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.CinemaHipError(
+                f"the CINeMA hot path runs on an MI355X only (got device '{device}'); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.desc = desc
+        self.device = device
+        self.layout = param_layout(desc)
+        self.flat = torch.zeros(desc.n_params, device=device, dtype=torch.float32)
+        self.flat_grad = torch.zeros(desc.n_params, device=device, dtype=torch.float32)
+        pk_dt = torch.bfloat16 if desc.precision == _lib.PREC_BF16 else torch.float32
+        self.packed = torch.zeros(desc.pk_total, device=device, dtype=pk_dt)
+        self.ws: Optional[Workspace] = None
+        self.version = 0          # bumped by every forward: guards stale backward calls
+        self._packed_version = None
+
+    # -- views ------------------------------------------------------------------------
+    def param_views(self, flat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        flat = self.flat if flat is None else flat
+        out = {}
+        for key, off, shape in self.layout:
+            n = 1
+            for s in shape:
+                n *= s
+            out[key] = flat[off:off + n].view(shape)
+        return out
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, n_rows: int) -> Workspace:
+        if self.ws is None or self.ws.npad_cap < round_up(n_rows, ROW_ALIGN):
+            self.ws = None
+            self.ws = Workspace(self.desc, n_rows, self.device, self.desc.in_dim)
+        return self.ws
+
+    # -- steps ------------------------------------------------------------------------
+    def pack(self):
+        """Refresh the packed compute copies from the flat fp32 parameters (one launch)."""
+        check(self.lib.cinema_siren_pack(C.byref(self.desc), ptr(self.flat), ptr(self.packed), self.stream()),
+              "cinema_siren_pack")
+
+    def forward(self, n: int) -> torch.Tensor:
+        """Run the stack on ws.coords_t / ws.lat (already filled for n rows). Returns ws.out."""
+        ws = self.ws
+        npad = round_up(n, ROW_ALIGN)
+        self.version += 1
+        check(self.lib.cinema_siren_forward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
+                                            ptr(ws.lat), n, npad, ptr(ws.saved), ptr(ws.out), self.stream()),
+              "cinema_siren_forward")
+        return ws.out
+
+    def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True):
+        """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords."""
+        ws = self.ws
+        ws.ensure_backward()
+        npad = round_up(n, ROW_ALIGN)
+        flags = 0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS
+        check(self.lib.cinema_siren_backward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
+                                             ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n, npad, ptr(ws.gbuf),
+                                             ptr(self.flat_grad), ptr(ws.dlat), ptr(ws.dcoords), flags, self.stream()),
+              "cinema_siren_backward")
+
+
+class TrilerpState:
+    """Buffers of the K1 stage for one latent table."""
+
+    def __init__(self):
+        self.shadow = None
+        self.affine = None
+        self.work = None
+
+
+def k1_forward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
+               cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int):
+    """transform + latent gather + trilinear interpolation into eng.ws.coords_t / eng.ws.lat."""
+    lib, d, ws = eng.lib, eng.desc, eng.ws
+    S, Cc = latents.shape[0], latents.shape[1]
+    lx, ly, lz = latents.shape[2], latents.shape[3], latents.shape[4]
+    G = lx * ly * lz
+    cond_dims = 0 if cond is None else cond.shape[1]
+    if Cc + cond_dims != d.lat:
+        raise ValueError(f"latent channels {Cc} + condition dims {cond_dims} != lat_size {d.lat} of the SIREN")
+    if st.shadow is None or st.shadow.numel() != S * G * Cc:
+        st.shadow = torch.empty(S, G, Cc, device=eng.device, dtype=torch.float32)
+    s = eng.stream()
+    check(lib.cinema_latent_to_node_major(ptr(latents), S, Cc, G, ptr(st.shadow), s), "cinema_latent_to_node_major")
+    aff = None
+    if tfs is not None:
+        rows = tfs.shape[0]
+        if st.affine is None or st.affine.shape[0] < rows:
+            st.affine = torch.empty(rows, 12, device=eng.device, dtype=torch.float32)
+        check(lib.cinema_affine_from_embedding(ptr(tfs), rows, tfs.shape[1], ptr(st.affine), s),
+              "cinema_affine_from_embedding")
+        aff = st.affine
+    npad = round_up(n, ROW_ALIGN)
+    check(lib.cinema_affine_trilerp_fwd(ptr(coords), ptr(idx), ptr(aff), 1 if tf_per_sample else 0, ptr(st.shadow),
+                                        ptr(cond) if cond_dims else None, n, npad, S, Cc, lx, ly, lz, cond_dims,
+                                        d.precision, ptr(ws.coords_t), ptr(ws.lat), d.LP, s),
+          "cinema_affine_trilerp_fwd")
+
+
+def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
+                cond_dims: int, tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int,
+                want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None):
+    """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords."""
+    lib, d, ws = eng.lib, eng.desc, eng.ws
+    S, Cc, lx, ly, lz = latents_shape
+    need = 2 * S + 2 + n
+    if st.work is None or st.work.numel() < need:
+        st.work = torch.empty(need, device=eng.device, dtype=torch.int32)
+    dlatents = torch.empty(S, Cc, lx, ly, lz, device=eng.device, dtype=torch.float32) if want_latents else None
+    dtfs = None
+    if tfs is not None:
+        if dtf_out is not None:
+            dtfs = dtf_out
+        elif tf_per_sample:
+            dtfs = torch.empty(n, tfs.shape[1], device=eng.device, dtype=torch.float32)
+        else:
+            dtfs = torch.zeros(tfs.shape[0], tfs.shape[1], device=eng.device, dtype=torch.float32)
+    dcond = torch.empty(n, cond_dims, device=eng.device, dtype=torch.float32) if (want_cond and cond_dims) else None
+    npad = round_up(n, ROW_ALIGN)
+    check(lib.cinema_affine_trilerp_bwd(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
+                                        1 if tf_per_sample else 0, ptr(st.affine) if tfs is not None else None,
+                                        ptr(st.shadow), ptr(ws.coords_t), ptr(ws.dlat), ptr(ws.dcoords), n, npad, S, Cc,
+                                        lx, ly, lz, cond_dims, d.LP, ptr(dlatents), ptr(dtfs), ptr(dcond), ptr(st.work),
+                                        eng.stream()),
+          "cinema_affine_trilerp_bwd")
+    return dlatents, dtfs, dcond
+
+
+def sample_loss(eng_or_device, out: torch.Tensor, n: int, sr_dims: int, n_cls: int, loss_metric: str,
+                class_w: Optional[torch.Tensor], sr_scale: float, seg_scale: float, dout: torch.Tensor,
+                sums: torch.Tensor, target: Optional[torch.Tensor] = None, voxel: Optional[torch.Tensor] = None,
+                subj: Optional[torch.Tensor] = None, intens: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None, voxels_per_subject: int = 0,
+                target_out: Optional[torch.Tensor] = None):
+    """K3: GT sampling + loss sums + dLoss/dOutput in one launch (see include/cinema_hip.h)."""
+    lib = _lib.load()
+    device = out.device
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    npad = min(round_up(n, ROW_ALIGN), dout.shape[0])
+    check(lib.cinema_sample_loss_fwd_bwd(ptr(out), ptr(target), ptr(voxel), ptr(subj), ptr(intens), ptr(labels),
+                                         voxels_per_subject, n, npad, sr_dims, n_cls, 0 if loss_metric == "mse" else 1,
+                                         ptr(class_w), float(sr_scale), float(seg_scale), ptr(sums), ptr(dout),
+                                         ptr(target_out), stream), "cinema_sample_loss_fwd_bwd")

@@ -1,0 +1,175 @@
+"""torch.autograd.Functions that route the reference's module API into libcinema_hip.so."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import engine as E
+
+
+class DecoderState:
+    """Per-module mutable state shared between forward and backward."""
+
+    def __init__(self, eng: E.SirenEngine):
+        self.engine = eng
+        self.k1 = E.TrilerpState()
+        self.pack_sig = None
+
+
+def _as_f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _maybe_pack(state: DecoderState, params):
+    sig = tuple(p._version for p in params) + (state.engine.flat.data_ptr(),)
+    if sig != state.pack_sig:
+        state.engine.pack()
+        state.pack_sig = sig
+
+
+class DecoderFunction(torch.autograd.Function):
+    """INR_Decoder.forward of the reference (models/inr_decoder.py:24-36) as ONE autograd node:
+    transform -> [idcs_df] gather -> trilinear interpolation -> Siren."""
+
+    @staticmethod
+    def forward(ctx, state: DecoderState, coords, latents, cond, tfs, idx, tf_per_sample: bool, *params):
+        eng = state.engine
+        dev = eng.device
+        n = coords.shape[0]
+        coords_c = _as_f32(coords, dev)
+        lat_c = _as_f32(latents, dev)
+        cond_c = _as_f32(cond, dev) if (cond is not None and cond.shape[-1] > 0) else None
+        tfs_c = _as_f32(tfs, dev) if tfs is not None else None
+        idx_c = idx.detach().to(device=dev, dtype=torch.int32).contiguous()
+        eng.workspace(n)
+        _maybe_pack(state, params)
+        E.k1_forward(eng, state.k1, coords_c, idx_c, lat_c, cond_c, tfs_c, tf_per_sample, n)
+        out = eng.forward(n)[:n].clone()
+        ctx.state, ctx.n, ctx.version = state, n, eng.version
+        ctx.tf_per_sample = tf_per_sample
+        ctx.lat_shape = tuple(lat_c.shape)
+        ctx.cond_dims = 0 if cond_c is None else cond_c.shape[1]
+        ctx.has_cond = cond is not None
+        ctx.cond_shape = None if cond is None else tuple(cond.shape)
+        ctx.save_for_backward(coords_c, idx_c, tfs_c if tfs_c is not None else coords_c.new_empty(0))
+        ctx.has_tfs = tfs_c is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, n = ctx.state, ctx.n
+        eng = state.engine
+        if eng.version != ctx.version:
+            raise RuntimeError("cinema_amd: the saved activations of this forward were overwritten by a later forward of "
+                               "the same module; call backward() before the next forward (or use a separate module copy)")
+        coords_c, idx_c, tfs_c = ctx.saved_tensors
+        tfs_c = tfs_c if ctx.has_tfs else None
+        ws = eng.ws
+        ws.ensure_backward()
+        npad = E.round_up(n, E.ROW_ALIGN)
+        ws.dout[:n].copy_(gout)
+        if npad > n:
+            ws.dout[n:npad].zero_()
+        need = ctx.needs_input_grad
+        want_w = any(need[7:])
+        eng.backward(n, ws.dout, weight_grads=want_w)
+        want_lat, want_cond, want_tf = need[2], ctx.has_cond and need[3], ctx.has_tfs and need[4]
+        dlat, dtfs, dcond = E.k1_backward(eng, state.k1, coords_c, idx_c, ctx.lat_shape, ctx.cond_dims,
+                                          tfs_c if want_tf else None, ctx.tf_per_sample, n,
+                                          want_latents=want_lat, want_cond=want_cond)
+        if ctx.has_cond and need[3] and dcond is None:   # zero-width condition tensor
+            dcond = torch.zeros(ctx.cond_shape, device=eng.device)
+        pgrads = [None] * (len(need) - 7)
+        if want_w:
+            g = eng.flat_grad.clone()
+            for k, (key, off, shape) in enumerate(eng.layout):
+                if need[7 + k]:
+                    cnt = 1
+                    for s in shape:
+                        cnt *= s
+                    pgrads[k] = g[off:off + cnt].view(shape)
+        return (None, None, dlat, dcond, dtfs, None, None, *pgrads)
+
+
+class SirenFunction(torch.autograd.Function):
+    """Siren.forward of the reference (models/siren.py:59-61) on explicit (coords, latent) rows."""
+
+    @staticmethod
+    def forward(ctx, state: DecoderState, coords, latent, *params):
+        eng = state.engine
+        n = coords.shape[0]
+        ws = eng.workspace(n)
+        _maybe_pack(state, params)
+        npad = E.round_up(n, E.ROW_ALIGN)
+        ws.coords_t[:npad].zero_()
+        ws.coords_t[:n].copy_(coords.detach())
+        ws.lat[:npad].zero_()
+        ws.lat[:n, :eng.desc.lat].copy_(latent.detach())
+        out = eng.forward(n)[:n].clone()
+        ctx.state, ctx.n, ctx.version = state, n, eng.version
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, n = ctx.state, ctx.n
+        eng = state.engine
+        if eng.version != ctx.version:
+            raise RuntimeError("cinema_amd: saved activations were overwritten by a later forward of the same Siren")
+        ws = eng.ws
+        ws.ensure_backward()
+        npad = E.round_up(n, E.ROW_ALIGN)
+        ws.dout[:n].copy_(gout)
+        if npad > n:
+            ws.dout[n:npad].zero_()
+        need = ctx.needs_input_grad
+        want_w = any(need[3:])
+        eng.backward(n, ws.dout, weight_grads=want_w)
+        dcoords = ws.dcoords[:n].clone() if need[1] else None
+        dlat = ws.dlat[:n, :eng.desc.lat].clone() if need[2] else None
+        pgrads = [None] * (len(need) - 3)
+        if want_w:
+            g = eng.flat_grad.clone()
+            for k, (key, off, shape) in enumerate(eng.layout):
+                if need[3 + k]:
+                    cnt = 1
+                    for s in shape:
+                        cnt *= s
+                    pgrads[k] = g[off:off + cnt].view(shape)
+        return (None, dcoords, dlat, *pgrads)
+
+
+class LossFunction(torch.autograd.Function):
+    """Criterion's data terms (utils.py:84-95) with the gradient w.r.t. the network output
+    produced in the same launch.  Returns (total_data, sr_mean, ce_mean); only `total_data`
+    = sr_scale*sr_mean + seg_scale*ce_mean carries gradient."""
+
+    @staticmethod
+    def forward(ctx, output, target, sr_dims: int, loss_metric: str, class_w: Optional[torch.Tensor], sr_scale: float,
+                seg_scale: float):
+        n, od = output.shape
+        dev = output.device
+        out_c = output.detach().contiguous().float()
+        tgt_c = target.detach().to(device=dev, dtype=torch.float32).contiguous()
+        npad = E.round_up(n, E.ROW_ALIGN)
+        dout = torch.empty(npad, od, device=dev, dtype=torch.float32)
+        sums = torch.empty(4, device=dev, dtype=torch.float32)
+        cw = None if class_w is None else class_w.detach().to(device=dev, dtype=torch.float32).contiguous()
+        E.sample_loss(None, out_c, n, sr_dims, od - sr_dims, loss_metric, cw, sr_scale, seg_scale, dout, sums,
+                      target=tgt_c)
+        sr_mean = sums[0] / float(n * sr_dims)
+        if seg_scale > 0:
+            den = sums[2] if cw is not None else float(n)
+            ce_mean = sums[1] / den
+        else:
+            ce_mean = torch.zeros((), device=dev)
+        total = sr_scale * sr_mean + seg_scale * ce_mean
+        ctx.save_for_backward(dout)
+        ctx.n = n
+        ctx.mark_non_differentiable(sr_mean, ce_mean)
+        return total, sr_mean, ce_mean
+
+    @staticmethod
+    def backward(ctx, g_total, g_sr, g_ce):
+        (dout,) = ctx.saved_tensors
+        return dout[:ctx.n] * g_total, None, None, None, None, None, None

@@ -1,0 +1,145 @@
+"""Drop-in for the reference's `models/inr_decoder.py` (INR_Decoder, Modulator, LatentRegressor).
+
+Same constructor (`INR_Decoder(args, device)`), `forward(coords, latent_vecs, condition_vecs,
+tfs=None, idcs_df=None)`, `inference(...)`, static `transform` / `spatial_interpolation`, and the
+same state_dict keys (`sr_net.net.{i}.linear.*`, `sr_net.net.{i}.linear_lats.*`,
+`sr_net.final_linear.*`, `modulator.conv.*`).  `forward` is one autograd node that calls the
+fused HIP path: per-sample affine registration -> latent gather by subject id (no (N,C,lx,ly,lz)
+materialisation) -> trilinear interpolation -> SIREN stack.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import engine as E
+from ..functions import DecoderFunction
+from .siren import Siren
+
+
+class Modulator(nn.Module):
+    """Reference: models/inr_decoder.py:109-123.  Identity for kernel_size == 0 (the default,
+    config_atlas.yaml:74), else Conv3d(C, C, k, padding='same') over the latent table (run by
+    MIOpen through torch; it acts on the (S,C,lx,ly,lz) table, not on the sample stream)."""
+
+    def __init__(self, latent_dims, kernel_size=3):
+        super().__init__()
+        if kernel_size > 0:
+            self.conv = nn.Conv3d(latent_dims[0], latent_dims[0], kernel_size, padding="same")
+        else:
+            self.conv = nn.Identity()
+
+    def forward(self, latent_vecs):
+        return self.conv(latent_vecs)
+
+
+class LatentRegressor(nn.Module):
+    """Reference: models/inr_decoder.py:126-141 (tiny 3-layer MLP on pooled latents; off the hot path)."""
+
+    def __init__(self, latent_dims):
+        super().__init__()
+        self.sequence = nn.Sequential(nn.Linear(latent_dims[0], 64), nn.ReLU(), nn.Linear(64, 32), nn.ReLU(),
+                                      nn.Linear(32, 1))
+
+    def forward(self, latent_vecs):
+        return self.sequence(latent_vecs)
+
+
+class INR_Decoder(nn.Module):
+    def __init__(self, args, device):
+        super().__init__()
+        self.args = args
+        a = args["inr_decoder"]
+        self.device = device
+        self.sr_dims = sum(a["out_dim"][:-1])
+        self.out_dim = sum(a["out_dim"])
+        self.mod_dim = a["hidden_size"] * len(a["modulated_layers"]) * 2
+        self.modulator = Modulator(a["latent_dim"], kernel_size=a["cnn_kernel_size"])
+        precision = a.get("precision", None)
+        if isinstance(precision, str):
+            precision = _lib.PREC_BF16 if precision.lower() in ("bf16", "bfloat16") else _lib.PREC_F32
+        if precision is None:
+            precision = E.default_precision(args.get("amp", None))
+        self.sr_net = Siren(a["in_dim"], a["latent_dim"][0] + a["cond_dims"], self.out_dim, a["hidden_size"],
+                            a["num_hidden_layers"], f_om=a["omega"][0], h_om=a["omega"][1], outermost_linear=True,
+                            modulated_layers=a["modulated_layers"], precision=precision)
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, coords, latent_vecs, condition_vecs, tfs=None, idcs_df=None, tf_table: bool = False):
+        """
+        coords (N,3); latent_vecs (S,C,lx,ly,lz) -- the whole subject table; condition_vecs (N,c) or
+        None; tfs (N,6|9|12) per sample as in the reference, or the (S,d) table when tf_table=True
+        (extension: rows are then picked by idcs_df inside the kernel); idcs_df (N,) subject ids.
+        Returns (N, sum(out_dim)).
+        """
+        if idcs_df is None:
+            if latent_vecs.shape[0] != coords.shape[0] and latent_vecs.shape[0] != 1:
+                raise ValueError("idcs_df is required unless latent_vecs has one grid per sample (or a single grid)")
+            idcs_df = (torch.arange(coords.shape[0], device=coords.device) if latent_vecs.shape[0] != 1
+                       else torch.zeros(coords.shape[0], dtype=torch.int32, device=coords.device))
+        st = self.sr_net.hot_state(coords.device)
+        n = coords.shape[0]
+        if n == 0:
+            return coords.new_zeros((0, self.out_dim))
+        if idcs_df.dim() != 1:
+            idcs_df = idcs_df.reshape(-1)
+        if idcs_df.shape[0] != n:
+            raise ValueError(f"idcs_df has {idcs_df.shape[0]} entries for {n} coordinates")
+        if tfs is not None and not tf_table and tfs.shape[0] != n:
+            raise ValueError(f"tfs has {tfs.shape[0]} rows for {n} coordinates (pass tf_table=True for a per-subject table)")
+        table = self.modulator(latent_vecs)
+        if table.dim() != 5:
+            raise ValueError("latent_vecs must be (S, C, lx, ly, lz)")
+        return DecoderFunction.apply(st, coords, table, condition_vecs, tfs, idcs_df, not tf_table, *st.param_list)
+
+    # ------------------------------------------------------------------------------------
+    def inference(self, coords, latent_vec, condition_vec, img_shape, tfs=None, step_size=100000):
+        """Dense volume evaluation (reference: models/inr_decoder.py:38-62): chunked forward, then
+        clamp / per-modality whole-volume min-max / argmax / softmax / channel concat, all on the GPU.
+        Returns (X, Y, Z, sr_dims + 1 + n_cls) fp32."""
+        dev = coords.device
+        n = coords.shape[0]
+        output = torch.empty((n, self.out_dim), device=dev, dtype=torch.float32)
+        idx0 = torch.zeros(min(step_size, n), dtype=torch.int32, device=dev)
+        tf_row = None if tfs is None else tfs.reshape(1, -1)
+        cond = condition_vec.reshape(1, -1).to(dev)
+        with torch.no_grad():
+            for i in range(0, n, step_size):
+                c = coords[i:i + step_size]
+                m = c.shape[0]
+                cv = cond.expand(m, -1)
+                output[i:i + m] = self.forward(c, latent_vec, cv, tf_row, idcs_df=idx0[:m], tf_table=tfs is not None)
+        lib = _lib.load()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        sr = self.sr_dims
+        minmax = torch.cat((torch.ones(sr, device=dev), torch.zeros(sr, device=dev)))
+        vol = torch.empty((n, sr + 1 + (self.out_dim - sr)), device=dev, dtype=torch.float32)
+        _lib.check(lib.cinema_infer_minmax(_lib.ptr(output), n, self.out_dim, sr, _lib.ptr(minmax), stream),
+                   "cinema_infer_minmax")
+        _lib.check(lib.cinema_infer_finish(_lib.ptr(output), n, self.out_dim, sr, _lib.ptr(minmax), _lib.ptr(vol), stream),
+                   "cinema_infer_finish")
+        modalities_rec = vol.reshape(list(img_shape) + [-1])
+        if self.args.get("mask_reconstruction", False):
+            from ..postmask import mask_reconstruction
+            return mask_reconstruction(modalities_rec, sr, self.args["dataset"]["label_names"])
+        return modalities_rec
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def transform(coords, tfs, inverse=False):
+        """c' = A(tfs) c + t per sample (reference: models/inr_decoder.py:64-71) through the K1 kernels."""
+        if inverse:
+            raise NotImplementedError("inverse=True is unused by the reference's callers and not built")
+        from ..functions_static import TransformFunction
+        return TransformFunction.apply(coords, tfs)
+
+    @staticmethod
+    def spatial_interpolation(coords, latents, condition_vecs=None):
+        """Trilinear interpolation of PER-SAMPLE grids latents (N,C,lx,ly,lz) at coords (N,3)
+        (reference: models/inr_decoder.py:73-85), through the K1 kernels with idx = arange(N)."""
+        from ..functions_static import InterpFunction
+        return InterpFunction.apply(coords, latents, condition_vecs)

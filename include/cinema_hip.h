@@ -1,0 +1,173 @@
+/*
+ * cinema_hip.h -- C ABI of libcinema_hip.so: the MI355X (gfx950) kernels behind CINeMA's
+ * conditional-INR hot path.
+ *
+ * The reference (m-dannecker/CINeMA) is pure Python/PyTorch and has NO FFI layer; its
+ * boundary for this path is the Python module API of models/inr_decoder.py and
+ * models/siren.py.  Each entry point below therefore cites the
+ * reference Python code whose arithmetic it replaces.  The Python mirror of that module
+ * API (cinema_amd/models/) binds these symbols with ctypes (cinema_amd/_lib.py);
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer unless marked "host"; sizes are explicit;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     performs no device synchronisation;
+ *   - return value: 0 = ok, otherwise a hipError_t or a negative library code;
+ *     cinema_last_error() returns a thread-local description of the last failure;
+ *   - the caller (PyTorch) owns every buffer; the library allocates nothing.
+ *   - precision: 0 = fp32 (exact-f32 MFMA), 1 = bf16 (bf16 MFMA, fp32 accumulate).  The
+ *     element type "T" of activation / packed-weight buffers follows it.
+ *   - Npad = N rounded up to a multiple of 128.  Row buffers have Npad rows; rows >= N are
+ *     written as zeros (inputs) or finite don't-cares (activations) by the library.
+ */
+#ifndef CINEMA_HIP_H
+#define CINEMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CINEMA_MAX_LAYERS 16
+#define CINEMA_PREC_F32 0
+#define CINEMA_PREC_BF16 1
+
+/* Flags for cinema_siren_backward */
+#define CINEMA_BWD_SKIP_WEIGHT_GRADS 1 /* frozen MLP (validation latent fitting, build_atlas.py:99-126) */
+
+int cinema_version(void);
+const char *cinema_last_error(void);
+
+/* -------------------------------------------------------------------------------------
+ * SIREN stack description.  Mirrors Siren.__init__ (models/siren.py:40-57) and the sizes
+ * INR_Decoder.__init__ derives (models/inr_decoder.py:14-22).  The caller fills the first
+ * block and calls cinema_siren_plan(), which fills the derived block.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cinema_siren_desc {
+  /* --- caller-filled --- */
+  int32_t n_layers;        /* sine layers incl. the first one = num_hidden_layers + 1 */
+  int32_t in_dim;          /* coordinate dimension (3) */
+  int32_t hidden;          /* hidden_size; must be a multiple of 16 */
+  int32_t lat;             /* latent_dim[0] + cond_dims (siren lat_size) */
+  int32_t out_dim;         /* sum(out_dim) <= 16 */
+  int32_t precision;       /* CINEMA_PREC_* */
+  uint32_t modulated_mask; /* bit i set <=> layer i in modulated_layers */
+  float omega_first;       /* f_om */
+  float omega_hidden;      /* h_om */
+  /* --- derived by cinema_siren_plan --- */
+  int32_t HP;              /* hidden rounded up to 64 */
+  int32_t LP;              /* lat rounded up to 64 */
+  int32_t n_saved;         /* number of [Npad x HP] T tensors in the saved-activation buffer */
+  int32_t n_gbuf;          /* number of [Npad x HP] T tensors in the backward scratch buffer */
+  /* offsets in floats into the flat fp32 parameter / gradient buffer (natural nn.Linear
+   * layouts, state_dict order of the reference: final_linear first, siren.py:50-57) */
+  int64_t off_w[CINEMA_MAX_LAYERS], off_b[CINEMA_MAX_LAYERS];
+  int64_t off_wl[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS]; /* -1 if not modulated */
+  int64_t off_wf, off_bf, n_params;
+  /* offsets in elements of T into the packed compute copy of the weights */
+  int64_t pk_w[CINEMA_MAX_LAYERS], pk_wt[CINEMA_MAX_LAYERS];
+  int64_t pk_wls[CINEMA_MAX_LAYERS], pk_wlt[CINEMA_MAX_LAYERS];
+  int64_t pk_wlsT[CINEMA_MAX_LAYERS], pk_wltT[CINEMA_MAX_LAYERS];
+  int64_t pk_wf, pk_total;
+  /* slot indices ([Npad x HP] tensors) */
+  int32_t sv_y[CINEMA_MAX_LAYERS], sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
+  int32_t gb_z[CINEMA_MAX_LAYERS], gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS];
+} cinema_siren_desc;
+
+int cinema_siren_plan(cinema_siren_desc *d /* host */);
+
+/* fp32 master parameters -> packed, zero-padded compute copies (W, W^T, linear_lats split
+ * into scale/shift halves and their transposes, final_linear padded to 16 rows).  One
+ * launch.  Replaces nothing in the reference: it is the layout change that lets
+ * siren.py:30-35 run as MFMA GEMMs. */
+int cinema_siren_pack(const cinema_siren_desc *d /* host */, const float *params, void *packed, void *stream);
+
+/* Siren.forward (models/siren.py:59-61) incl. every SineLayer.forward (siren.py:26-36):
+ *   out[n, :] = final_linear(cat(x_L, lat)),  x_{l+1} = sin(w z) | sin(w z s + t).
+ * coords_t [Npad x 3] fp32 (registered coordinates), lat [Npad x LP] T,
+ * saved [n_saved x Npad x HP] T (kept for backward), out [Npad x out_dim] fp32. */
+int cinema_siren_forward(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                         const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
+                         float *out, void *stream);
+
+/* Backward of the above (what autograd does for siren.py:26-36,59-61).
+ * dout [Npad x out_dim] fp32 (rows >= N must be zero), gbuf [n_gbuf x Npad x HP] T scratch,
+ * grad_params [n_params] fp32 (zeroed by this call, then accumulated with atomics),
+ * dlat [Npad x LP] fp32 (overwritten), dcoords [Npad x 3] fp32 (overwritten). */
+int cinema_siren_backward(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                          const float *coords_t, const void *lat, const void *saved, const float *dout,
+                          int64_t N, int64_t Npad, void *gbuf, float *grad_params, float *dlat,
+                          float *dcoords, int32_t flags, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * K1: affine registration + trilinear latent gather.
+ * ------------------------------------------------------------------------------------- */
+
+/* embed2affine + euler2rot (utils.py:126-166): rows x tf_dim (6|9|12) -> rows x 12
+ * (A row-major 3x3, then t). */
+int cinema_affine_from_embedding(const float *embed, int64_t rows, int32_t tf_dim, float *affine, void *stream);
+
+/* latent table (S, C, G=lx*ly*lz) -> node-major shadow (S, G, C) so that the 8 corner
+ * reads of one sample are contiguous in C (replaces the per-sample grid materialisation
+ * `modulator(latent_vecs)[idcs_df]`, models/inr_decoder.py:33). */
+int cinema_latent_to_node_major(const float *latents, int64_t S, int32_t C, int32_t G, float *shadow, void *stream);
+
+/* INR_Decoder.transform (models/inr_decoder.py:64-71) + [idcs_df] gather (:33) +
+ * spatial_interpolation (:73-85), fused.
+ *   coords [N x 3] fp32, idx [N] int32 in [0,S), affine [S|N x 12] fp32 or NULL (no tfs),
+ *   cond [N x cond_dims] fp32 or NULL,
+ *   coords_t [Npad x 3] fp32, lat_out [Npad x LP] T (cols >= C+cond_dims and rows >= N zero). */
+int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx, const float *affine,
+                              int32_t affine_per_sample, const float *shadow, const float *cond, int64_t N,
+                              int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                              int32_t cond_dims, int32_t precision, float *coords_t, void *lat_out, int32_t LP,
+                              void *stream);
+
+/* Backward of the above:
+ *   dlat [Npad x LP] fp32, dcoords_t [Npad x 3] fp32 (gradient reaching the registered
+ *   coordinates through the SIREN's first layer; the interpolation term is added here),
+ *   -> dlatents (S, C, G) fp32 (overwritten, deterministic per-subject reduction),
+ *      dembed: per-sample [N x tf_dim] (affine_per_sample) or table [S x tf_dim] (atomics;
+ *      caller zeroes), may be NULL,  dcond [N x cond_dims] or NULL.
+ *   work: int32 scratch of at least 2*S + 2 + N entries. */
+int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                              int32_t embed_per_sample, const float *affine, const float *shadow,
+                              const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
+                              int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                              float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * K3: ground-truth sampling + loss + dLoss/dOutput (Criterion.forward, utils.py:88-104,
+ * and the integer gather `vol[c_nz]` of data_loading/dataset.py:87-89).
+ *   target source A (dense):  target [N x (sr_dims+1)] fp32, last column = label.
+ *   target source B (volumes): voxel [N] int64 linear voxel index, subj [N] int32,
+ *     vol_int [n_mod pointers on device -> per-modality concatenated fp32 volumes],
+ *     given as intens [S*V x sr_dims] fp32 (subject-major, modality innermost) and
+ *     labels [S*V] uint8; V voxels per subject.
+ *   sums (fp32[4], zeroed by the call): [0] sum |d| or d^2, [1] sum w*nll, [2] sum w (pre-pass, only with class_w), [3] sum w
+ *   dout [Npad x out_dim] fp32 = d total / d output with
+ *     total = sr_scale*sr + seg_scale*ce   (sr_scale = sr_weight, seg_scale = seg_weight^2,
+ *     the reference applies seg_weight twice, utils.py:95,103).
+ *   class_w [n_cls] fp32 or NULL.  loss_metric: 0 = mse, 1 = l1.
+ * ------------------------------------------------------------------------------------- */
+int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                               const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                               int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                               float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                               void *stream);
+
+/* Dense-inference epilogue (models/inr_decoder.py:50-57): clamp, per-modality min/max over
+ * the whole volume (two passes: cinema_infer_minmax then cinema_infer_finish), argmax,
+ * softmax, channel concat -> vol [G x (sr_dims + 1 + n_cls)] fp32.
+ * minmax: fp32 [2*sr_dims] = mins then maxs; caller initialises mins to 1.0 and maxs to 0.0
+ * (values are clamped to [0,1] before the reduction). */
+int cinema_infer_minmax(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, float *minmax, void *stream);
+int cinema_infer_finish(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax,
+                        float *vol, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CINEMA_HIP_H */

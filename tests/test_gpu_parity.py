@@ -1,0 +1,283 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in modules) against
+ (a) the golden vectors generated from the reference's own modules, and
+ (b) the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star): max-norm relative error <= 1e-4 in fp32 mode and
+<= 2e-2 in bf16-MFMA mode on outputs, losses and gradients; labels / indices bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-4, "bf16": 2e-2}
+T = torch.from_numpy
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def make_args(latent_dim, hidden, layers, mod, out_dim, cond_dims, precision, loss_metric="mse", class_weights=None,
+              tf_weight=0.0):
+    return {
+        "inr_decoder": {"in_dim": 3, "out_dim": out_dim, "latent_dim": latent_dim, "cond_dims": cond_dims,
+                        "hidden_size": hidden, "num_hidden_layers": layers, "modulated_layers": mod,
+                        "omega": [30, 30], "cnn_kernel_size": 0, "tf_dim": 6, "precision": precision},
+        "optimizer": {"tf_weight": tf_weight, "loss_metric": loss_metric},
+        "dataset": {"class_weights": class_weights, "label_names": ["ClearLabel", "CSF", "cGM", "WM", "BG"]},
+        "mask_reconstruction": False, "device": "cuda:0",
+    }
+
+
+def test_library_loads_and_reports_version():
+    from cinema_amd import _lib
+    assert _lib.load().cinema_version() >= 100
+
+
+def test_g1_embed2affine():
+    from cinema_amd.utils import embed2affine, euler2rot
+    g = load_golden("g1_affine.npz")
+    for d in (6, 9, 12):
+        R, t = embed2affine(T(g[f"embed{d}"]).to(dev()))
+        assert rel_err(R.cpu().numpy(), g[f"R{d}"]) < 1e-5
+        assert np.array_equal(t.cpu().numpy(), g[f"t{d}"])
+    R = euler2rot(torch.tensor([[0.1, 0.2, 0.3]], device=dev()))
+    assert rel_err(R.cpu().numpy(), g["R_known"][:, :]) < 1e-5
+
+
+def test_g2_transform_fwd_bwd():
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    g = load_golden("g2_transform.npz")
+    for d in (6, 9, 12):
+        tfs = T(g[f"tfs{d}"]).to(dev()).requires_grad_(True)
+        y = INR_Decoder.transform(T(g[f"coords{d}"]).to(dev()), tfs)
+        assert rel_err(y.detach().cpu().numpy(), g[f"out{d}"]) < 1e-5
+        (y * T(g[f"gout{d}"]).to(dev())).sum().backward()
+        assert rel_err(tfs.grad.cpu().numpy(), g[f"gtfs{d}"]) < 1e-4, d
+
+
+@pytest.mark.parametrize("name", ["g333", "g111", "g234"])
+def test_g3_spatial_interpolation_fwd_bwd(name):
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    g = load_golden("g3_interp.npz")
+    lat_tab = T(g[f"{name}_lat"])
+    idx = T(g[f"{name}_idx"]).long()
+    lat = lat_tab[idx].to(dev()).requires_grad_(True)          # per-sample grids, as the reference passes them
+    c = T(g[f"{name}_coords"]).to(dev()).requires_grad_(True)
+    cond = T(g[f"{name}_cond"]).to(dev())
+    o = INR_Decoder.spatial_interpolation(c, lat, cond)
+    assert rel_err(o.detach().cpu().numpy(), g[f"{name}_out"]) < 1e-5
+    (o * T(g[f"{name}_gout"]).to(dev())).sum().backward()
+    glat = torch.zeros_like(lat_tab).index_add_(0, idx, lat.grad.cpu())
+    assert rel_err(glat.numpy(), g[f"{name}_glat"]) < 1e-5
+    ref_gc = g[f"{name}_gcoords"]
+    assert np.abs(c.grad.cpu().numpy() - ref_gc).max() <= 1e-5 * max(1.0, np.abs(ref_gc).max())
+
+
+def _load_decoder(g, latent_dim, hidden, layers, mod, out_dim, cond, precision, tf_weight=0.1):
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import Criterion
+    ncls = out_dim[-1]
+    args = make_args(latent_dim, hidden, layers, mod, out_dim, cond, precision, loss_metric="mse",
+                     class_weights=[0.0] + [1.0] * (ncls - 1), tf_weight=tf_weight)
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    sd = {k[2:]: T(g[k]) for k in g.files if k.startswith("p_")}
+    assert list(dec.state_dict().keys()) == list(g["state_keys"])
+    dec.load_state_dict(sd)
+    return dec, Criterion(args)
+
+
+CFGS = {
+    "cfgT": dict(latent_dim=[32, 1, 1, 1], hidden=128, layers=3, mod=[1, 3], out_dim=[1, 10], cond=0),
+    "cfgS": dict(latent_dim=[16, 2, 3, 4], hidden=64, layers=2, mod=[0, 2], out_dim=[2, 5], cond=2),
+    "cfgV": dict(latent_dim=[65, 3, 3, 3], hidden=128, layers=5, mod=[1, 3, 5], out_dim=[1, 10], cond=1),
+    "cfgD": dict(latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[2, 10], cond=0),
+}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["cfgT", "cfgS", "cfgV", "cfgD"])
+def test_g5_decoder_golden(name, precision):
+    """Full INR_Decoder forward + Criterion + backward against the reference's own outputs."""
+    c = CFGS[name]
+    g = load_golden(f"g5_decoder_{name}.npz")
+    dec, crit = _load_decoder(g, c["latent_dim"], c["hidden"], c["layers"], c["mod"], c["out_dim"], c["cond"], precision)
+    tol = TOL[precision]
+    lat = T(g["lat"]).to(dev()).requires_grad_(True)
+    tft = T(g["tft"]).to(dev()).requires_grad_(True)
+    cond = T(g["cond"]).to(dev()).requires_grad_(True)
+    coords, target = T(g["coords"]).to(dev()), T(g["target"]).to(dev())
+    idx = T(g["idx"]).to(dev())
+    tfs = tft[idx.long()]
+    out = dec(coords, lat, cond, tfs, idcs_df=idx)
+    loss = crit(out, target, tfs, seg_weight=1.0)
+    loss["total"].backward()
+    errs = {"out": rel_err(out.detach().cpu().numpy(), g["out"])}
+    for k in ("total", "sr", "seg", "tf"):
+        errs["loss_" + k] = abs(float(loss[k]) - float(g["loss_" + k])) / max(abs(float(g["loss_" + k])), 1e-12)
+    errs["glat"] = rel_err(lat.grad.cpu().numpy(), g["glat"])
+    errs["gtft"] = rel_err(tft.grad.cpu().numpy(), g["gtft"])
+    if c["cond"] > 0:
+        errs["gcond"] = rel_err(cond.grad.cpu().numpy(), g["gcond"])
+    for n, p in dec.named_parameters():
+        errs["g_" + n] = rel_err(p.grad.cpu().numpy(), g["g_" + n])
+    bad = {k: v for k, v in errs.items() if not (v < tol)}
+    assert not bad, f"{name}/{precision}: rel-err above {tol}: {bad}\nall: {errs}"
+
+
+def test_g6_criterion_golden():
+    from cinema_amd.utils import Criterion
+    g = load_golden("g6_criterion.npz")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        metric, segw, cwtag, tfd = g[pre + "meta"]
+        cw = list(g[pre + "cw"]) if cwtag == "w" else None
+        args = make_args([8, 1, 1, 1], 16, 1, [1], [2, 10], 0, "fp32", loss_metric=str(metric), class_weights=cw, tf_weight=0.3)
+        crit = Criterion(args)
+        o = T(g[pre + "out"]).to(dev()).requires_grad_(True)
+        tfs = T(g[pre + "tfs"]).to(dev()).requires_grad_(True)
+        loss = crit(o, T(g[pre + "target"]).to(dev()), tfs, seg_weight=float(segw))
+        assert set(loss.keys()) == {"seg", "sr", "trafo", "total", "tf_rot", "tf_trans", "tf_scale", "tf"}
+        loss["total"].backward()
+        for k in ("seg", "sr", "total", "tf_rot", "tf_trans", "tf_scale", "tf"):
+            ref = float(g[pre + "loss_" + k])
+            assert abs(float(loss[k]) - ref) <= 1e-5 * max(abs(ref), 1e-3), (c, k, float(loss[k]), ref)
+        assert rel_err(o.grad.cpu().numpy(), g[pre + "gout"]) < 1e-4, c
+        assert rel_err(tfs.grad.cpu().numpy(), g[pre + "gtfs"]) < 1e-4, c
+    # tfs=None raises KeyError like the reference (utils.py:103)
+    with pytest.raises(KeyError):
+        crit(o, T(g[pre + "target"]).to(dev()), None)
+
+
+def _oracle_case(N, S, latent_dim, hidden, layers, mod, out_dim, cond, seed, precision, loss_metric="mse", tf_table=False):
+    from oracle import cinema_oracle as O
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import Criterion
+    gen = torch.Generator().manual_seed(seed)
+    ncls = out_dim[-1]
+    sr = sum(out_dim[:-1])
+    cw = [0.0] + [1.0 + 0.25 * (i % 3) for i in range(ncls - 1)]
+    args = make_args(latent_dim, hidden, layers, mod, out_dim, cond, precision, loss_metric=loss_metric, class_weights=cw,
+                     tf_weight=0.05)
+    torch.manual_seed(seed)
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    crit = Criterion(args)
+    lat = (torch.randn(S, *latent_dim, generator=gen) * 0.05)
+    tft = (torch.rand(S, 6, generator=gen) - 0.5) * 0.1
+    coords = torch.rand(N, 3, generator=gen) * 1.9 - 0.95
+    idx = torch.randint(0, S, (N,), generator=gen, dtype=torch.int32)
+    condv = torch.randn(N, cond, generator=gen) * 0.05
+    target = torch.cat((torch.rand(N, sr, generator=gen), torch.randint(1, ncls, (N, 1), generator=gen).float()), 1)
+    # oracle on CPU
+    params = {k[len("sr_net."):]: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    lat_o, tft_o, cond_o = (x.clone().requires_grad_(True) for x in (lat, tft, condv))
+    cfg = dict(num_hidden_layers=layers, omega=[30, 30], sr_dims=sr, loss_metric=loss_metric,
+               class_weights=torch.tensor(cw), tf_weight=0.05)
+    loss_o, out_o = O.training_step(params, lat_o, tft_o, coords, target, idx, cond_o, cfg)
+    # HIP path
+    lat_g, tft_g, cond_g = (x.to(dev()).requires_grad_(True) for x in (lat, tft, condv))
+    idx_g = idx.to(dev())
+    if tf_table:
+        out = dec(coords.to(dev()), lat_g, cond_g, tft_g, idcs_df=idx_g, tf_table=True)
+        tfs_for_loss = tft_g[idx_g.long()]
+    else:
+        tfs_for_loss = tft_g[idx_g.long()]
+        out = dec(coords.to(dev()), lat_g, cond_g, tfs_for_loss, idcs_df=idx_g)
+    loss = crit(out, target.to(dev()), tfs_for_loss, seg_weight=1.0)
+    loss["total"].backward()
+    errs = {"out": rel_err(out.detach().cpu().numpy(), out_o.detach().numpy()),
+            "loss": abs(float(loss["total"]) - float(loss_o["total"])) / abs(float(loss_o["total"])),
+            "glat": rel_err(lat_g.grad.cpu().numpy(), lat_o.grad.numpy()),
+            "gtft": rel_err(tft_g.grad.cpu().numpy(), tft_o.grad.numpy())}
+    if cond:
+        errs["gcond"] = rel_err(cond_g.grad.cpu().numpy(), cond_o.grad.numpy())
+    for n, p in dec.named_parameters():
+        errs["g_" + n] = rel_err(p.grad.cpu().numpy(), params[n[len("sr_net."):]].grad.numpy())
+    return errs
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_oracle_parity_ragged_batch(precision):
+    """N not a multiple of the 128-row tile, many subjects some of which get no sample, L1 loss."""
+    errs = _oracle_case(N=1000, S=37, latent_dim=[48, 3, 3, 3], hidden=256, layers=4, mod=[1, 3], out_dim=[2, 10], cond=1,
+                        seed=11, precision=precision, loss_metric="l1")
+    bad = {k: v for k, v in errs.items() if not (v < TOL[precision])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_oracle_parity_dhcp_shape_tf_table(precision):
+    """cfg-D dimensions (latent 256x3^3, hidden 512, out 2+10) at N = 4096, S = 16; tf table mode."""
+    errs = _oracle_case(N=4096, S=16, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[2, 10],
+                        cond=0, seed=12, precision=precision, tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < TOL[precision])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
+def test_tiny_batch_and_single_sample():
+    """N = 1 and N = 3 (far below one tile): shapes stay (N, out) and values match the oracle."""
+    for n in (1, 3):
+        errs = _oracle_case(N=n, S=2, latent_dim=[32, 1, 1, 1], hidden=128, layers=3, mod=[1, 3], out_dim=[1, 10], cond=0,
+                            seed=13 + n, precision="fp32")
+        bad = {k: v for k, v in errs.items() if not (v < 1e-4)}
+        assert not bad, f"N={n}: {bad}"
+
+
+def test_empty_batch():
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    args = make_args([32, 1, 1, 1], 128, 3, [1, 3], [1, 10], 0, "bf16")
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    out = dec(torch.zeros(0, 3, device=dev()), torch.zeros(2, 32, 1, 1, 1, device=dev()), torch.zeros(0, 0, device=dev()),
+              None, idcs_df=torch.zeros(0, dtype=torch.int32, device=dev()))
+    assert out.shape == (0, 11)
+
+
+def test_cpu_tensors_fail_loudly():
+    from cinema_amd import _lib
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    args = make_args([32, 1, 1, 1], 128, 3, [1, 3], [1, 10], 0, "bf16")
+    dec = INR_Decoder(args, "cpu")
+    with pytest.raises(_lib.CinemaHipError):
+        dec(torch.zeros(4, 3), torch.zeros(2, 32, 1, 1, 1), torch.zeros(4, 0), None, idcs_df=torch.zeros(4, dtype=torch.int32))
+
+
+def test_g10_inference_volume():
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    g = load_golden("g10_inference.npz")
+    args = make_args([16, 3, 3, 3], 64, 2, [1, 2], [2, 5], 1, "fp32")
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    dec.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("p_")})
+    coords, lat, cond, tf = (T(g[k]).to(dev()) for k in ("coords", "lat", "cond", "tf"))
+    vol = dec.inference(coords, lat, cond, [12, 12, 12], None, step_size=500).cpu().numpy()
+    ref = g["vol"]
+    assert vol.shape == ref.shape
+    assert np.array_equal(np.isnan(vol), np.isnan(ref))
+    # hard labels: identical except where the two top logits tie at fp32 noise level
+    assert (vol[..., 2] != ref[..., 2]).mean() < 1e-3
+    assert np.abs(np.nan_to_num(vol[..., 3:]) - np.nan_to_num(ref[..., 3:])).max() < 1e-4      # soft labels
+    assert np.abs(np.nan_to_num(vol[..., :2]) - np.nan_to_num(ref[..., :2])).max() < 1e-3      # min-max scaled intensities
+    vol_tf = dec.inference(coords, lat, cond, [12, 12, 12], tf, step_size=500).cpu().numpy()
+    assert np.abs(np.nan_to_num(vol_tf[..., 3:]) - np.nan_to_num(g["vol_tf"][..., 3:])).max() < 1e-4
+
+
+def test_state_dict_roundtrip_and_deepcopy():
+    import copy
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    args = make_args([32, 1, 1, 1], 128, 3, [1, 3], [1, 10], 0, "bf16")
+    torch.manual_seed(0)
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    x = (torch.rand(50, 3, device=dev()) * 2 - 1, torch.randn(2, 32, 1, 1, 1, device=dev()) * 0.1)
+    idx = torch.randint(0, 2, (50,), device=dev(), dtype=torch.int32)
+    y0 = dec(x[0], x[1], torch.zeros(50, 0, device=dev()), None, idcs_df=idx)
+    dec2 = copy.deepcopy(dec)
+    y1 = dec2(x[0], x[1], torch.zeros(50, 0, device=dev()), None, idcs_df=idx)
+    assert torch.equal(y0, y1)
+    sd = {k: v.cpu() for k, v in dec.state_dict().items()}
+    dec3 = INR_Decoder(args, "cuda:0").to(dev())
+    dec3.load_state_dict(sd)
+    y2 = dec3(x[0], x[1], torch.zeros(50, 0, device=dev()), None, idcs_df=idx)
+    assert torch.equal(y0, y2)
