@@ -9,7 +9,23 @@ namespace {
 // small helpers
 // ----------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void sincos_t(float a, float &s, float &c);
-template <> __device__ __forceinline__ void sincos_t<float>(float a, float &s, float &c) { sincosf(a, &s, &c); }
+template <> __device__ __forceinline__ void sincos_t<float>(float a, float &s, float &c) {
+  // fp32-accurate sin/cos without the library's scratch-backed Payne-Hanek path: three-term Cody-Waite
+  // reduction by pi/2 (exact products for |a| < ~1e5; SIREN phases are O(100)) + minimax polynomials on
+  // [-pi/4, pi/4] (Cephes sinf/cosf coefficients).  |error| <= ~2 ulp.
+  const float k = rintf(a * 0.636619772367581343f);
+  float r = fmaf(-k, 1.5703125f, a);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188216e-8f, r);
+  const float r2 = r * r;
+  const float ps = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float pc = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                        fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k & 3;
+  const float sv = (q & 1) ? pc : ps, cv = (q & 1) ? ps : pc;
+  s = (q & 2) ? -sv : sv;
+  c = ((q + 1) & 2) ? -cv : cv;
+}
 template <> __device__ __forceinline__ void sincos_t<bf16_t>(float a, float &s, float &c) {
   s = __sinf(a);
   c = __cosf(a);
