@@ -12,6 +12,7 @@ import os
 MAX_LAYERS = 16
 PREC_F32, PREC_BF16 = 0, 1
 BWD_SKIP_WEIGHT_GRADS = 1
+BWD_PHASE_CHAIN, BWD_PHASE_DLAT, BWD_PHASE_DW, BWD_PHASE_FINAL_DW = 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcinema_hip.so")

@@ -756,17 +756,20 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
                          float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s) {
   const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP, nl = d->n_layers;
   const bool wgrads = !(flags & CINEMA_BWD_SKIP_WEIGHT_GRADS);
+  const int phases = (flags & CINEMA_BWD_PHASE_MASK) ? (flags & CINEMA_BWD_PHASE_MASK) : CINEMA_BWD_PHASE_MASK;
+  const bool all_phases = phases == CINEMA_BWD_PHASE_MASK;
   const T *pk = (const T *)packed;
   const T *sv = (const T *)saved;
   T *gb = (T *)gbuf;
   const size_t slot = (size_t)Npad * HP;
   const int tiles_f = (HP + 127) / 128;
   const int grid = tiles_f * (int)(Npad / 128);
-  if (wgrads) CINEMA_CHECK_HIP(hipMemsetAsync(gp, 0, sizeof(float) * (size_t)d->n_params, s));
-  CINEMA_CHECK_HIP(hipMemsetAsync(dcoords, 0, sizeof(float) * (size_t)Npad * d->in_dim, s));
+  if (wgrads && all_phases) CINEMA_CHECK_HIP(hipMemsetAsync(gp, 0, sizeof(float) * (size_t)d->n_params, s));
+  if (phases & CINEMA_BWD_PHASE_CHAIN)
+    CINEMA_CHECK_HIP(hipMemsetAsync(dcoords, 0, sizeof(float) * (size_t)Npad * d->in_dim, s));
 
   // ---- chain ----
-  for (int i = nl - 1; i >= 0; --i) {
+  for (int i = nl - 1; i >= 0 && (phases & CINEMA_BWD_PHASE_CHAIN); --i) {
     const bool mod = (d->modulated_mask >> i) & 1u;
     const bool top = i == nl - 1, first = i == 0;
     BwdArgs a = {};
@@ -809,7 +812,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   }
 
   // ---- d lat ----
-  {
+  if (phases & CINEMA_BWD_PHASE_DLAT) {
     DlatArgs a = {};
     int ns = 0;
     for (int i = 0; i < nl; ++i)
@@ -835,7 +838,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   if (!wgrads) return 0;
 
   // ---- weight gradients: one grouped launch ----
-  {
+  if (phases & CINEMA_BWD_PHASE_DW) {
     DwArgs a = {};
     int np = 0, tiles = 0;
     auto add = [&](const void *P, const void *Q, float *out, int ldp, int ldq, int ldo, int M, int K) {
@@ -871,7 +874,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     }
   }
   // ---- final_linear weight / bias gradients ----
-  {
+  if (phases & CINEMA_BWD_PHASE_FINAL_DW) {
     FinalBwdArgs a = {};
     a.X = sv + slot * d->sv_y[nl - 1]; a.ldx = HP; a.H = H;
     a.LAT = lat; a.LP = LP; a.lat = L;

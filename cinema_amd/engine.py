@@ -149,12 +149,12 @@ class SirenEngine:
               "cinema_siren_forward")
         return ws.out
 
-    def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True):
+    def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0):
         """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords."""
         ws = self.ws
         ws.ensure_backward()
         npad = round_up(n, ROW_ALIGN)
-        flags = 0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS
+        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | phases
         check(self.lib.cinema_siren_backward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
                                              ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n, npad, ptr(ws.gbuf),
                                              ptr(self.flat_grad), ptr(ws.dlat), ptr(ws.dcoords), flags, self.stream()),
@@ -201,14 +201,18 @@ def k1_forward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: to
 
 def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
                 cond_dims: int, tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int,
-                want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None):
+                want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None,
+                dlat_out: Optional[torch.Tensor] = None):
     """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents_shape
     need = 2 * S + 2 + n
     if st.work is None or st.work.numel() < need:
         st.work = torch.empty(need, device=eng.device, dtype=torch.int32)
-    dlatents = torch.empty(S, Cc, lx, ly, lz, device=eng.device, dtype=torch.float32) if want_latents else None
+    dlatents = None
+    if want_latents:
+        dlatents = dlat_out if dlat_out is not None else torch.empty(S, Cc, lx, ly, lz, device=eng.device,
+                                                                      dtype=torch.float32)
     dtfs = None
     if tfs is not None:
         if dtf_out is not None:

@@ -1,0 +1,204 @@
+"""Data-parallel hot loop of CINeMA's AtlasBuilder (reference: build_atlas.py:48-97, 414-463) on MI355X.
+
+One process per GPU.  Subjects -- their latent grids, rigid/affine embeddings, resident volumes,
+foreground lists and AdamW moments -- are SHARDED across ranks (each subject lives on exactly one
+rank); the SIREN weights are replicated and only their 8.46 MB flat gradient is all-reduced
+(RCCL over xGMI through torch.distributed), overlapped with the latent-side backward + optimiser.
+
+A step is the reference's inner loop body (build_atlas.py:69-90): zero_grad -> forward -> loss ->
+backward -> AdamW, on `n_samples` coordinates sliced from the epoch's shuffled foreground list.
+It calls the C ABI directly (no autograd graph): pack -> K1 -> SIREN fwd -> K3 -> SIREN bwd ->
+K1 bwd -> optimiser.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .models.inr_decoder import INR_Decoder
+
+
+class SubjectStore:
+    """Resident ground truth of this rank's subjects + the epoch's shuffled sample list.
+
+    intens (S*V, sr_dims) fp32 and labels (S*V,) uint8 are the (normalised) modality volumes in
+    C-order; `coords`, `voxel`, `subj` list every foreground voxel of every local subject
+    (data_loading/dataset.py:83-98) and are permuted once per epoch like collate_fn
+    (dataset.py:36-47) so that a step is a contiguous slice."""
+
+    def __init__(self, intens: torch.Tensor, labels: torch.Tensor, voxels_per_subject: int, coords: torch.Tensor,
+                 voxel: torch.Tensor, subj: torch.Tensor, conditions: Optional[torch.Tensor] = None):
+        self.intens, self.labels, self.V = intens, labels, int(voxels_per_subject)
+        self.coords, self.voxel, self.subj = coords, voxel, subj
+        self.conditions = conditions          # (S, cond_dims) normalised, or None
+        self.n_subjects = labels.numel() // self.V
+
+    def __len__(self):
+        return self.coords.shape[0]
+
+    def shuffle(self, generator: Optional[torch.Generator] = None):
+        perm = torch.randperm(len(self), device=self.coords.device, generator=generator)
+        self.coords = self.coords[perm]
+        self.voxel = self.voxel[perm]
+        self.subj = self.subj[perm]
+
+    @staticmethod
+    def synthetic(n_subjects: int, shape, spacing: float, world_bbox, sr_dims: int, n_labels: int, seed: int, device,
+                  cond_dims: int = 0, cond_scale: float = 0.05):
+        from . import synthetic as syn
+        V = shape[0] * shape[1] * shape[2]
+        intens = torch.empty(n_subjects * V, sr_dims, device=device, dtype=torch.float32)
+        labels = torch.empty(n_subjects * V, device=device, dtype=torch.uint8)
+        cs, vs, ss = [], [], []
+        for s in range(n_subjects):
+            it, lb, aff = syn.make_subject(shape, spacing, sr_dims, n_labels, seed * 100003 + s, device)
+            intens[s * V:(s + 1) * V] = it
+            labels[s * V:(s + 1) * V] = lb
+            c, v = syn.foreground_lists(lb, shape, aff, world_bbox)
+            cs.append(c)
+            vs.append(v)
+            ss.append(torch.full((v.shape[0],), s, dtype=torch.int32, device=device))
+            del it, lb
+        cond = None
+        if cond_dims:
+            g = torch.Generator().manual_seed(seed + 17)
+            cond = ((torch.rand(n_subjects, cond_dims, generator=g) * 2 - 1) * cond_scale).to(device)
+        return SubjectStore(intens, labels, V, torch.cat(cs), torch.cat(vs), torch.cat(ss), cond)
+
+
+class HotPathTrainer:
+    def __init__(self, args: dict, store: SubjectStore, device, process_group=None, split: str = "train",
+                 decoder: Optional[INR_Decoder] = None):
+        import torch.distributed as dist
+        self.args, self.store, self.device, self.split = args, store, torch.device(device), split
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        a, o = args["inr_decoder"], args["optimizer"]
+        self.sr_dims = sum(a["out_dim"][:-1])
+        self.n_cls = a["out_dim"][-1]
+        self.cond_dims = a["cond_dims"]
+        self.decoder = decoder if decoder is not None else INR_Decoder(args, str(self.device)).to(self.device)
+        self.state = self.decoder.sr_net.hot_state(self.device)
+        self.eng = self.state.engine
+        self.k1 = self.state.k1
+        S = store.n_subjects
+        tf_w = max(a["tf_dim"], 6)
+        # parameter tables (reference: build_atlas.py:414-425)
+        self.latents = nn.Parameter(torch.normal(0, 0.01, size=(S, *a["latent_dim"])).to(self.device))
+        self.tfs = nn.Parameter(torch.zeros(S, tf_w, device=self.device), requires_grad=a["tf_dim"] > 0)
+        self.lat_grad = torch.zeros_like(self.latents)
+        self.tf_grad = torch.zeros_like(self.tfs)
+        self.flat_param = nn.Parameter(self.eng.flat)
+        self.flat_param.grad = self.eng.flat_grad
+        self.train_mlp = split == "train"
+        self.seg_weight = o["seg_weight"] if split == "train" else 0.0      # build_atlas.py:63
+        cw = args["dataset"]["class_weights"]
+        self.class_w = torch.tensor(cw, dtype=torch.float32, device=self.device) if cw is not None else None
+        self.cond_param = None
+        if split == "val" and self.cond_dims:
+            self.cond_param = nn.Parameter(torch.normal(0, 0.01, size=(S, self.cond_dims)).to(self.device))
+        groups = [{"params": [self.latents], "lr": o["lr_latent"], "weight_decay": o["latent_weight_decay"]}]
+        if a["tf_dim"] > 0:
+            groups.append({"params": [self.tfs], "lr": o["lr_tf"], "weight_decay": o["tf_weight_decay"]})
+        if self.cond_param is not None:
+            groups.append({"params": [self.cond_param], "lr": o["lr_latent"], "weight_decay": o["latent_weight_decay"]})
+        self.opt_local = torch.optim.AdamW(groups, fused=True)
+        self.opt_mlp = (torch.optim.AdamW([{"params": [self.flat_param], "lr": o["lr_inr"],
+                                            "weight_decay": o["inr_weight_decay"]}], fused=True)
+                        if self.train_mlp else None)
+        self.schedulers = []
+        if o.get("scheduler", {}).get("type") == "cosine":
+            T = args["epochs"][split]
+            for opt in (self.opt_local, self.opt_mlp):
+                if opt is not None:
+                    self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
+        self.sums = torch.zeros(4, device=self.device)
+        self.n_last = 0
+        self.tf_weight = o["tf_weight"]
+        self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
+
+    # ------------------------------------------------------------------------------------
+    def step(self, lo: int, hi: int):
+        """One optimisation step on samples [lo, hi) of the epoch list (build_atlas.py:69-88)."""
+        import torch.distributed as dist
+        st, eng = self.store, self.eng
+        coords, voxel, subj = st.coords[lo:hi], st.voxel[lo:hi], st.subj[lo:hi]
+        n = coords.shape[0]
+        ws = eng.workspace(n)
+        ws.ensure_backward()
+        cond = None
+        if self.cond_dims:
+            table = self.cond_param.data if self.cond_param is not None else st.conditions
+            cond = table[subj.long()].contiguous()
+        tfs = self.tfs.data
+        eng.pack()
+        E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
+        eng.forward(n)
+        E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
+                      float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
+                      labels=st.labels, voxels_per_subject=st.V)
+        eng.backward(n, ws.dout, weight_grads=self.train_mlp)
+        work = None
+        if self.train_mlp and self.world > 1:
+            work = dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        want_tf = self.tfs.requires_grad
+        if want_tf:
+            self.tf_grad.zero_()
+        _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
+                                    tfs if want_tf else None, False, n, want_latents=True,
+                                    want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
+                                    dlat_out=self.lat_grad)
+        if want_tf and self.tf_weight != 0.0:
+            self._add_tf_regulariser_grad(subj, n)
+        self.latents.grad = self.lat_grad
+        if want_tf:
+            self.tfs.grad = self.tf_grad
+        if self.cond_param is not None:
+            g = torch.zeros_like(self.cond_param)
+            g.index_add_(0, subj.long(), dcond)
+            self.cond_param.grad = g
+        self.opt_local.step()
+        if work is not None:
+            work.wait()
+        if self.opt_mlp is not None:
+            self.opt_mlp.step()
+        self.n_last = n
+
+    def _add_tf_regulariser_grad(self, subj, n):
+        """d/d table of tf_weight * (mean(tfs[idx,0:3]^2) + mean(tfs[idx,3:6]^2) [+ scale term])  (utils.py:98-103)."""
+        counts = torch.bincount(subj.long(), minlength=self.tfs.shape[0]).to(torch.float32).unsqueeze(1)
+        w = self.tfs.shape[1]
+        scale = torch.zeros(w, device=self.device)
+        scale[:6] = 1.0
+        if w == 9:
+            scale[6:9] = 1.0
+        self.tf_grad.add_(self.tfs.data * counts * scale * (2.0 * self.tf_weight / (3.0 * n)))
+
+    def epoch(self, n_samples: int, generator: Optional[torch.Generator] = None, max_steps: Optional[int] = None):
+        """One pass over the shuffled foreground list in chunks of n_samples (build_atlas.py:65-68)."""
+        self.store.shuffle(generator)
+        m = len(self.store)
+        steps = 0
+        for lo in range(0, m, n_samples):
+            self.step(lo, min(lo + n_samples, m))
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+        for s in self.schedulers:
+            s.step()
+        return steps
+
+    def loss_dict(self) -> Dict[str, float]:
+        """Losses of the LAST step with the reference's keys (one device->host sync; call every k steps)."""
+        s = self.sums.tolist()
+        n = max(self.n_last, 1)
+        sr = s[0] / (n * self.sr_dims)
+        den = s[2] if self.class_w is not None else float(n)
+        ce = s[1] / den if (self.seg_weight > 0 and den > 0) else 0.0
+        out = {"sr": sr, "seg": self.seg_weight * ce, "trafo": 0.0}
+        out["total"] = out["sr"] + self.seg_weight * out["seg"]
+        return out

@@ -36,6 +36,12 @@ extern "C" {
 
 /* Flags for cinema_siren_backward */
 #define CINEMA_BWD_SKIP_WEIGHT_GRADS 1 /* frozen MLP (validation latent fitting, build_atlas.py:99-126) */
+/* Phase selection (profiling / roofline timing of one kernel at a time).  No phase bit set = all phases. */
+#define CINEMA_BWD_PHASE_CHAIN 4     /* per-layer dX GEMMs with the fused sine-derivative epilogues */
+#define CINEMA_BWD_PHASE_DLAT 8      /* d lat GEMM */
+#define CINEMA_BWD_PHASE_DW 16       /* grouped weight-gradient GEMMs (one launch) */
+#define CINEMA_BWD_PHASE_FINAL_DW 32 /* final_linear weight / bias gradients */
+#define CINEMA_BWD_PHASE_MASK 60
 
 int cinema_version(void);
 const char *cinema_last_error(void);
