@@ -95,3 +95,16 @@ def check(rc: int, what: str = ""):
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+ADAMW_MAX_GROUPS = 8
+
+
+class AdamWGroup(C.Structure):
+    """Mirror of `cinema_adamw_group` (include/cinema_hip.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step", C.c_int32)]
+
+
+SIGNATURES["cinema_adamw_step"] = [C.POINTER(AdamWGroup), _I32, _P]

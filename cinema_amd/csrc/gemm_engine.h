@@ -23,6 +23,11 @@
 
 #define WG_THREADS 256
 
+// LDS pointers carry their address space explicitly: a generic char* selected at run time (double
+// buffering) makes hipcc fall back to flat_load for the fragment reads, which also drains vmcnt.
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS char lds_char;
+
 template <typename T>
 struct Engine;
 
@@ -58,17 +63,17 @@ struct Engine<bf16_t> {
       s.b[it] = *reinterpret_cast<const u32x4 *>(B + (size_t)row * ldB + k0 + ch * 8);
     }
   }
-  __device__ static __forceinline__ void nt_store(const Stage &s, char *sA, char *sB, int tid) {
+  __device__ static __forceinline__ void nt_store(const Stage &s, lds_char *sA, lds_char *sB, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int q = tid + WG_THREADS * it;
       const int row = q >> 3, ch = q & 7;
       const int pr = perm_feature_row(row);
-      *reinterpret_cast<u32x4 *>(sA + pr * 128 + ((ch ^ ((pr >> 1) & 7)) << 4)) = s.a[it];
-      *reinterpret_cast<u32x4 *>(sB + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = s.b[it];
+      *(LDS_AS u32x4 *)(sA + pr * 128 + ((ch ^ ((pr >> 1) & 7)) << 4)) = s.a[it];
+      *(LDS_AS u32x4 *)(sB + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = s.b[it];
     }
   }
-  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const char *sA, const char *sB, int wf,
+  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const lds_char *sA, const lds_char *sB, int wf,
                                                     int wn, int lane) {
     const int i = lane & 15, gk = lane >> 4;
 #pragma unroll
@@ -78,9 +83,9 @@ struct Engine<bf16_t> {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int ra = wf * 64 + t * 16 + i;
-        a[t] = *reinterpret_cast<const bf16x8 *>(sA + ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4));
+        a[t] = *(const LDS_AS bf16x8 *)(sA + ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4));
         const int rb = wn * 64 + t * 16 + i;
-        b[t] = *reinterpret_cast<const bf16x8 *>(sB + rb * 128 + ((ch ^ ((rb >> 1) & 7)) << 4));
+        b[t] = *(const LDS_AS bf16x8 *)(sB + rb * 128 + ((ch ^ ((rb >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
@@ -108,21 +113,21 @@ struct Engine<bf16_t> {
     const int key = (row & 3) | (((row >> 3) & 1) << 2);
     return row * 256 + ((((colbyte >> 4) ^ (key << 1)) << 4) | (colbyte & 15));
   }
-  __device__ static __forceinline__ void tn_store(const Stage &s, char *sP, char *sQ, int tid) {
+  __device__ static __forceinline__ void tn_store(const Stage &s, lds_char *sP, lds_char *sQ, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int q = tid + WG_THREADS * it;
       const int row = q >> 4, ch = q & 15;
       const int off = tn_off(row, ch * 16);
-      *reinterpret_cast<u32x4 *>(sP + off) = s.a[it];
-      *reinterpret_cast<u32x4 *>(sQ + off) = s.b[it];
+      *(LDS_AS u32x4 *)(sP + off) = s.a[it];
+      *(LDS_AS u32x4 *)(sQ + off) = s.b[it];
     }
   }
-  __device__ static __forceinline__ bf16x8 tr_frag(const char *tile, int nbase, int colbase, int lane) {
+  __device__ static __forceinline__ bf16x8 tr_frag(const lds_char *tile, int nbase, int colbase, int lane) {
     // lanes 16g..16g+15 fetch rows nbase+8g+{0..7} of 16 columns; lane 4q+p addresses row q, columns 4p..4p+3
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int r0 = nbase + 8 * g + q;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef LDS_AS s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (lds_s16x4 *)(tile + tn_off(r0, (colbase + 4 * p) * 2)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -130,8 +135,10 @@ struct Engine<bf16_t> {
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   }
-  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const char *sP, const char *sQ, int wh, int wk,
-                                                    int lane) {
+  // nht: number of 16-row output tiles of this wave that hold valid rows (wave-uniform; narrow problems skip the rest)
+  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const lds_char *sP, const lds_char *sQ, int wh, int wk,
+                                                    int lane, int nht) {
+    if (nht <= 0) return;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 a[4], b[4];
@@ -142,9 +149,11 @@ struct Engine<bf16_t> {
       }
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht)
+        if (ht < nht) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+          for (int kt = 0; kt < 4; ++kt)
+            acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+        }
     }
   }
 };
@@ -176,19 +185,19 @@ struct Engine<float> {
       s.b[it] = *reinterpret_cast<const f32x4 *>(B + (size_t)row * ldB + k0 + ch * 4);
     }
   }
-  __device__ static __forceinline__ void nt_store(const Stage &s, char *sA, char *sB, int tid) {
-    float *fA = reinterpret_cast<float *>(sA), *fB = reinterpret_cast<float *>(sB);
+  __device__ static __forceinline__ void nt_store(const Stage &s, lds_char *sA, lds_char *sB, int tid) {
+    LDS_AS float *fA = (LDS_AS float *)sA, *fB = (LDS_AS float *)sB;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int q = tid + WG_THREADS * it;
       const int row = q >> 2, ch = q & 3;
-      *reinterpret_cast<f32x4 *>(fA + perm_feature_row(row) * NT_ROW + ch * 4) = s.a[it];
-      *reinterpret_cast<f32x4 *>(fB + row * NT_ROW + ch * 4) = s.b[it];
+      *(LDS_AS f32x4 *)(fA + perm_feature_row(row) * NT_ROW + ch * 4) = s.a[it];
+      *(LDS_AS f32x4 *)(fB + row * NT_ROW + ch * 4) = s.b[it];
     }
   }
-  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const char *sA, const char *sB, int wf,
+  __device__ static __forceinline__ void nt_compute(f32x4 (&acc)[4][4], const lds_char *sA, const lds_char *sB, int wf,
                                                     int wn, int lane) {
-    const float *fA = reinterpret_cast<const float *>(sA), *fB = reinterpret_cast<const float *>(sB);
+    const LDS_AS float *fA = (const LDS_AS float *)sA, *fB = (const LDS_AS float *)sB;
     const int i = lane & 15, gk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -218,19 +227,20 @@ struct Engine<float> {
       s.b[it] = *reinterpret_cast<const f32x4 *>(Q + (size_t)(n0 + row) * ldQ + cq);
     }
   }
-  __device__ static __forceinline__ void tn_store(const Stage &s, char *sP, char *sQ, int tid) {
-    float *fP = reinterpret_cast<float *>(sP), *fQ = reinterpret_cast<float *>(sQ);
+  __device__ static __forceinline__ void tn_store(const Stage &s, lds_char *sP, lds_char *sQ, int tid) {
+    LDS_AS float *fP = (LDS_AS float *)sP, *fQ = (LDS_AS float *)sQ;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int q = tid + WG_THREADS * it;
       const int row = q >> 5, ch = q & 31;
-      *reinterpret_cast<f32x4 *>(fP + row * TN_ROW + ch * 4) = s.a[it];
-      *reinterpret_cast<f32x4 *>(fQ + row * TN_ROW + ch * 4) = s.b[it];
+      *(LDS_AS f32x4 *)(fP + row * TN_ROW + ch * 4) = s.a[it];
+      *(LDS_AS f32x4 *)(fQ + row * TN_ROW + ch * 4) = s.b[it];
     }
   }
-  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const char *sP, const char *sQ, int wh, int wk,
-                                                    int lane) {
-    const float *fP = reinterpret_cast<const float *>(sP), *fQ = reinterpret_cast<const float *>(sQ);
+  __device__ static __forceinline__ void tn_compute(f32x4 (&acc)[4][4], const lds_char *sP, const lds_char *sQ, int wh, int wk,
+                                                    int lane, int nht) {
+    if (nht <= 0) return;
+    const LDS_AS float *fP = (const LDS_AS float *)sP, *fQ = (const LDS_AS float *)sQ;
     const int i = lane & 15, gk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -242,9 +252,11 @@ struct Engine<float> {
       }
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht)
+        if (ht < nht) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+          for (int kt = 0; kt < 4; ++kt)
+            acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht], b[kt], acc[ht][kt], 0, 0, 0);
+        }
     }
   }
 };
@@ -255,19 +267,18 @@ __device__ __forceinline__ void nt_mainloop(f32x4 (&acc)[4][4], const T *A, int 
                                             int K, char *smem) {
   using E = Engine<T>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wf = wave >> 1, wn = wave & 1;
-  char *sA[2] = {smem, smem + 2 * E::NT_TILE};
-  char *sB[2] = {smem + E::NT_TILE, smem + 3 * E::NT_TILE};
+  lds_char *base = (lds_char *)smem;   // buffer b: A tile at b*2*TILE, B tile right behind it
   typename E::Stage st;
   const int nt = K / E::BK;
   __syncthreads();  // LDS may still be read by a previous mainloop of this workgroup
   E::nt_load(st, A, ldA, rowsA, B, ldB, 0, tid);
-  E::nt_store(st, sA[0], sB[0], tid);
+  E::nt_store(st, base, base + E::NT_TILE, tid);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) E::nt_load(st, A, ldA, rowsA, B, ldB, (t + 1) * E::BK, tid);
-    E::nt_compute(acc, sA[cur], sB[cur], wf, wn, lane);
-    if (t + 1 < nt) E::nt_store(st, sA[cur ^ 1], sB[cur ^ 1], tid);
+    E::nt_compute(acc, base + cur * 2 * E::NT_TILE, base + cur * 2 * E::NT_TILE + E::NT_TILE, wf, wn, lane);
+    if (t + 1 < nt) E::nt_store(st, base + (cur ^ 1) * 2 * E::NT_TILE, base + (cur ^ 1) * 2 * E::NT_TILE + E::NT_TILE, tid);
     __syncthreads();
   }
 }
@@ -275,22 +286,21 @@ __device__ __forceinline__ void nt_mainloop(f32x4 (&acc)[4][4], const T *A, int 
 // acc += P[nbeg..nend, h0..]^T * Q[nbeg..nend, c0..]; nbeg/nend multiples of Engine::BN.
 template <typename T>
 __device__ __forceinline__ void tn_mainloop(f32x4 (&acc)[4][4], const T *P, int ldP, int h0, const T *Q, int ldQ,
-                                            int c0, int nbeg, int nend, char *smem) {
+                                            int c0, int nbeg, int nend, int nht, char *smem) {
   using E = Engine<T>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wh = wave >> 1, wk = wave & 1;
-  char *sP[2] = {smem, smem + 2 * E::TN_TILE};
-  char *sQ[2] = {smem + E::TN_TILE, smem + 3 * E::TN_TILE};
+  lds_char *base = (lds_char *)smem;
   typename E::Stage st;
   if (nbeg >= nend) return;  // uniform per workgroup
   E::tn_load(st, P, ldP, h0, Q, ldQ, c0, nbeg, tid);
-  E::tn_store(st, sP[0], sQ[0], tid);
+  E::tn_store(st, base, base + E::TN_TILE, tid);
   __syncthreads();
   int cur = 0;
   for (int n0 = nbeg; n0 < nend; n0 += E::BN) {
     const bool more = n0 + E::BN < nend;
     if (more) E::tn_load(st, P, ldP, h0, Q, ldQ, c0, n0 + E::BN, tid);
-    E::tn_compute(acc, sP[cur], sQ[cur], wh, wk, lane);
-    if (more) E::tn_store(st, sP[cur ^ 1], sQ[cur ^ 1], tid);
+    E::tn_compute(acc, base + cur * 2 * E::TN_TILE, base + cur * 2 * E::TN_TILE + E::TN_TILE, wh, wk, lane, nht);
+    if (more) E::tn_store(st, base + (cur ^ 1) * 2 * E::TN_TILE, base + (cur ^ 1) * 2 * E::TN_TILE + E::TN_TILE, tid);
     __syncthreads();
     cur ^= 1;
   }

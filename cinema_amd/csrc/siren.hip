@@ -332,8 +332,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
 // ----------------------------------------------------------------------------------------
 struct DwProb { const void *P; const void *Q; float *out; int ldp, ldq, ldo, M, K, tk; };
 struct DwArgs {
-  DwProb p[3 * CINEMA_MAX_LAYERS];
-  int tile_start[3 * CINEMA_MAX_LAYERS + 1];
+  DwProb p[3 * CINEMA_MAX_LAYERS + 2];
+  int tile_start[3 * CINEMA_MAX_LAYERS + 3];
   int nprob, splitk, Npad;
 };
 
@@ -356,8 +356,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
-  tn_mainloop<T>(acc, (const T *)pr.P, pr.ldp, h0, (const T *)pr.Q, pr.ldq, c0, nbeg, nend, smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wh = wave >> 1, wk = wave & 1;
+  const int rows_left = pr.M - h0 - wh * 64;                          // valid output rows of this wave
+  const int nht = __builtin_amdgcn_readfirstlane(rows_left <= 0 ? 0 : (rows_left >= 64 ? 4 : (rows_left + 15) >> 4));
+  tn_mainloop<T>(acc, (const T *)pr.P, pr.ldp, h0, (const T *)pr.Q, pr.ldq, c0, nbeg, nend, nht, smem);
   const int g = lane >> 4, i = lane & 15;
 #pragma unroll
   for (int ht = 0; ht < 4; ++ht)
@@ -435,63 +437,36 @@ __global__ __launch_bounds__(WG_THREADS) void k_final_fwd(FinalFwdArgs a) {
   }
 }
 
-// final_linear weight / bias gradients: dWf[o][k] = sum_n dOut[n][o] * [x_L | lat][n][k]
-struct FinalBwdArgs {
-  const void *X; int ldx; int H; const void *LAT; int LP; int lat;
-  const float *dout; int out_dim; float *dWf; float *dbf; int Npad;
-};
+struct FinalBwdArgs { const float *dout; int out_dim; float *dbf; int Npad; };
 
+// dOut [Npad x out_dim] fp32 -> [Npad x 16] T (zero padded) so that the final_linear weight gradient joins the
+// grouped TN launch as two more problems (P = dOut16, Q = x_L and Q = lat); also reduces the bias gradient.
 template <typename T>
-__global__ __launch_bounds__(WG_THREADS) void k_final_bwd_dw(FinalBwdArgs a) {
-  __shared__ float sd[32 * 16];
-  const int KT = a.H + a.lat;
-  const int rows_per = (a.Npad + gridDim.x - 1) / gridDim.x;
-  const int nbeg = blockIdx.x * rows_per;
-  const int nend = min(a.Npad, nbeg + rows_per);
-  constexpr int MAXC = 4;  // columns per thread: supports H + lat <= 1024 per pass
-  for (int cbase = 0; cbase < KT; cbase += WG_THREADS * MAXC) {
-    float acc[MAXC][16];
+__global__ __launch_bounds__(WG_THREADS) void k_dout_prep(FinalBwdArgs a, T *dout16) {
+  __shared__ float red[4][16];
+  float colsum[16];
 #pragma unroll
-    for (int m = 0; m < MAXC; ++m)
+  for (int o = 0; o < 16; ++o) colsum[o] = 0.f;
+  for (int n = blockIdx.x * WG_THREADS + threadIdx.x; n < a.Npad; n += gridDim.x * WG_THREADS) {
+    float v[16];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) acc[m][o] = 0.f;
-    for (int nb = nbeg; nb < nend; nb += 32) {
-      __syncthreads();
-      for (int q = threadIdx.x; q < 32 * 16; q += WG_THREADS) {
-        const int r = q >> 4, o = q & 15;
-        sd[q] = (nb + r < nend && o < a.out_dim) ? a.dout[(size_t)(nb + r) * a.out_dim + o] : 0.f;
-      }
-      __syncthreads();
-      const int rmax = min(32, nend - nb);
-      for (int r = 0; r < rmax; ++r) {
-#pragma unroll
-        for (int m = 0; m < MAXC; ++m) {
-          const int col = cbase + threadIdx.x + WG_THREADS * m;
-          if (col < KT) {
-            const float x = col < a.H ? to_f32(((const T *)a.X)[(size_t)(nb + r) * a.ldx + col])
-                                      : to_f32(((const T *)a.LAT)[(size_t)(nb + r) * a.LP + (col - a.H)]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[m][o] += sd[r * 16 + o] * x;
-          }
-        }
-      }
+    for (int o = 0; o < 16; ++o) {
+      v[o] = o < a.out_dim ? a.dout[(size_t)n * a.out_dim + o] : 0.f;
+      colsum[o] += v[o];
     }
-#pragma unroll
-    for (int m = 0; m < MAXC; ++m) {
-      const int col = cbase + threadIdx.x + WG_THREADS * m;
-      if (col < KT) {
-#pragma unroll
-        for (int o = 0; o < 16; ++o)
-          if (o < a.out_dim) atomicAdd(a.dWf + (size_t)o * KT + col, acc[m][o]);
-      }
-    }
+    store16(dout16 + (size_t)n * 16, v);
   }
-  // bias gradient: threads 0..15 sum their column over this block's rows
-  if (threadIdx.x < a.out_dim) {
-    float s = 0.f;
-    for (int n = nbeg; n < nend; ++n) s += a.dout[(size_t)n * a.out_dim + threadIdx.x];
-    atomicAdd(a.dbf + threadIdx.x, s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float s = colsum[o];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) red[wave][o] = s;
   }
+  __syncthreads();
+  if (threadIdx.x < a.out_dim && a.dbf != nullptr)
+    atomicAdd(a.dbf + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -588,7 +563,7 @@ extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
   d->n_params = off;
   d->pk_total = pk;
   d->n_saved = sv;
-  d->n_gbuf = gb;
+  d->n_gbuf = gb + 1;   // last slot: dOut as [Npad x 16] T for the final_linear weight gradient
   return 0;
 }
 
@@ -837,6 +812,15 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   }
   if (!wgrads) return 0;
 
+  // ---- final_linear: dOut -> [Npad x 16] T copy (operand of the grouped launch) + bias gradient ----
+  T *dout16 = gb + slot * (d->n_gbuf - 1);
+  if (phases & CINEMA_BWD_PHASE_FINAL_DW) {
+    FinalBwdArgs a = {};
+    a.dout = dout; a.out_dim = d->out_dim; a.dbf = all_phases ? gp + d->off_bf : nullptr; a.Npad = (int)Npad;
+    const int grid_f = (int)std::min<int64_t>((Npad + WG_THREADS - 1) / WG_THREADS, 256);
+    hipLaunchKernelGGL((k_dout_prep<T>), dim3(grid_f), dim3(WG_THREADS), 0, s, a, dout16);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
   // ---- weight gradients: one grouped launch ----
   if (phases & CINEMA_BWD_PHASE_DW) {
     DwArgs a = {};
@@ -855,33 +839,23 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
         add(gb + slot * d->gb_t[i], lat, gp + d->off_wl[i] + (size_t)H * L, HP, LP, L, H, L);
       }
     }
-    if (np > 0) {
-      a.tile_start[np] = tiles;
-      a.nprob = np;
-      a.Npad = (int)Npad;
-      const int ntile = (int)(Npad / Engine<T>::BN);
-      int splitk = std::max(1, 512 / std::max(tiles, 1));
-      splitk = std::min(splitk, std::max(1, ntile / 4));
-      a.splitk = splitk;
-      constexpr int smem = Engine<T>::TN_SMEM;
-      static bool attr_done = false;
-      if (!attr_done) {
-        if (int rc = set_smem_attr<T>((const void *)k_dw_grouped<T>, smem)) return rc;
-        attr_done = true;
-      }
-      hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * splitk), dim3(WG_THREADS), smem, s, a);
-      CINEMA_CHECK_HIP(hipGetLastError());
+    // final_linear.weight [out x (H + L)]: columns [0,H) against x_L, columns [H,H+L) against lat
+    add(dout16, sv + slot * d->sv_y[nl - 1], gp + d->off_wf, 16, HP, H + L, d->out_dim, H);
+    add(dout16, lat, gp + d->off_wf + H, 16, LP, H + L, d->out_dim, L);
+    a.tile_start[np] = tiles;
+    a.nprob = np;
+    a.Npad = (int)Npad;
+    const int ntile = (int)(Npad / Engine<T>::BN);
+    int splitk = std::max(1, 512 / std::max(tiles, 1));
+    splitk = std::min(splitk, std::max(1, ntile / 4));
+    a.splitk = splitk;
+    constexpr int smem = Engine<T>::TN_SMEM;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (int rc = set_smem_attr<T>((const void *)k_dw_grouped<T>, smem)) return rc;
+      attr_done = true;
     }
-  }
-  // ---- final_linear weight / bias gradients ----
-  if (phases & CINEMA_BWD_PHASE_FINAL_DW) {
-    FinalBwdArgs a = {};
-    a.X = sv + slot * d->sv_y[nl - 1]; a.ldx = HP; a.H = H;
-    a.LAT = lat; a.LP = LP; a.lat = L;
-    a.dout = dout; a.out_dim = d->out_dim;
-    a.dWf = gp + d->off_wf; a.dbf = gp + d->off_bf; a.Npad = (int)Npad;
-    const int grid_f = (int)std::min<int64_t>(Npad / 32, 256);
-    hipLaunchKernelGGL((k_final_bwd_dw<T>), dim3(grid_f), dim3(WG_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * splitk), dim3(WG_THREADS), smem, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   (void)N;

@@ -162,11 +162,8 @@ __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const floa
     g[10] = gsx.m[0][1] + gsz.m[2][1];
     g[11] = gsx.m[0][2] + gsy.m[1][2];
   }
-  if (per_sample) {
-    for (int k = 0; k < dim; ++k) dembed[n * dim + k] = g[k];
-  } else {
-    for (int k = 0; k < dim; ++k) atomicAdd(dembed + row * dim + k, g[k]);
-  }
+  // always one row per sample; in table mode k_tf_reduce sums the rows of each subject afterwards
+  for (int k = 0; k < dim; ++k) dembed[n * dim + k] = g[k];
 }
 
 __global__ void k_node_major(const float *lat, long S, int C, int G, float *shadow) {
@@ -327,11 +324,24 @@ __global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
 }
 
 // ---- grouping of the samples by subject (counting sort) ----
-__global__ void k_hist(const int32_t *idx, long N, long S, int32_t *counts) {
-  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
-    long s = idx[n];
-    s = s < 0 ? 0 : (s >= S ? S - 1 : s);
-    atomicAdd(counts + s, 1);
+// Both passes privatise the per-subject counters in LDS (one global atomic per non-empty bin per block)
+// when the subject count fits; each block owns the contiguous sample range [beg, end).
+#define GROUP_LDS_BINS 4096
+__device__ __forceinline__ long clamp_subject(long s, long S) { return s < 0 ? 0 : (s >= S ? S - 1 : s); }
+
+__global__ __launch_bounds__(256) void k_hist(const int32_t *idx, long N, long S, int32_t *counts) {
+  __shared__ int32_t bins[GROUP_LDS_BINS];
+  const long per = (N + gridDim.x - 1) / gridDim.x;
+  const long beg = blockIdx.x * per, end = beg + per < N ? beg + per : N;
+  if (S <= GROUP_LDS_BINS) {
+    for (int b = threadIdx.x; b < S; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    for (long n = beg + threadIdx.x; n < end; n += blockDim.x) atomicAdd(bins + clamp_subject(idx[n], S), 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < S; b += blockDim.x)
+      if (bins[b]) atomicAdd(counts + b, bins[b]);
+  } else {
+    for (long n = beg + threadIdx.x; n < end; n += blockDim.x) atomicAdd(counts + clamp_subject(idx[n], S), 1);
   }
 }
 __global__ void k_scan(int32_t *counts, long S, int32_t *offsets) {
@@ -361,12 +371,53 @@ __global__ void k_scan(int32_t *counts, long S, int32_t *offsets) {
   }
   if (threadIdx.x == 0) offsets[S] = carry;
 }
-__global__ void k_fill(const int32_t *idx, long N, long S, const int32_t *offsets, int32_t *cursor, int32_t *perm) {
-  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
-    long s = idx[n];
-    s = s < 0 ? 0 : (s >= S ? S - 1 : s);
-    const int pos = offsets[s] + atomicAdd(cursor + s, 1);
-    perm[pos] = (int32_t)n;
+__global__ __launch_bounds__(256) void k_fill(const int32_t *idx, long N, long S, const int32_t *offsets, int32_t *cursor,
+                                              int32_t *perm) {
+  __shared__ int32_t bins[GROUP_LDS_BINS];   // pass 1: block-local counts, then: next free slot of the block's range
+  const long per = (N + gridDim.x - 1) / gridDim.x;
+  const long beg = blockIdx.x * per, end = beg + per < N ? beg + per : N;
+  if (S <= GROUP_LDS_BINS) {
+    for (int b = threadIdx.x; b < S; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    for (long n = beg + threadIdx.x; n < end; n += blockDim.x) atomicAdd(bins + clamp_subject(idx[n], S), 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < S; b += blockDim.x) {
+      const int c = bins[b];
+      bins[b] = c ? offsets[b] + atomicAdd(cursor + b, c) : 0;
+    }
+    __syncthreads();
+    for (long n = beg + threadIdx.x; n < end; n += blockDim.x) {
+      const int pos = atomicAdd(bins + clamp_subject(idx[n], S), 1);
+      perm[pos] = (int32_t)n;
+    }
+  } else {
+    for (long n = beg + threadIdx.x; n < end; n += blockDim.x) {
+      const long s = clamp_subject(idx[n], S);
+      perm[offsets[s] + atomicAdd(cursor + s, 1)] = (int32_t)n;
+    }
+  }
+}
+
+// per-subject sum of the per-sample embedding gradients (table mode): one wave per subject, fixed order
+__global__ __launch_bounds__(256) void k_tf_reduce(const int32_t *offsets, const int32_t *perm, const float *dtf_ps, int dim,
+                                                   long S, float *dembed) {
+  const int lane = threadIdx.x & 63;
+  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (int p = offsets[s] + lane; p < offsets[s + 1]; p += 64) {
+    const float *r = dtf_ps + (long)perm[p] * dim;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (k < dim) acc[k] += r[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
+    if (lane == 0 && k < dim) dembed[s * dim + k] = acc[k];
   }
 }
 
@@ -387,6 +438,7 @@ __global__ __launch_bounds__(256) void k_lat_reduce(LatRedArgs a) {
   float *mine = acc + wave * G * 64;
   const int beg = a.offsets[s], end = a.offsets[s + 1];
   const int c = c0 + lane;
+  // generic grid: wave-private LDS table, plain read-modify-write (LDS float atomics serialise per lane: 3x slower)
   for (int p = beg + wave; p < end; p += 4) {
     const long n = a.perm[p];
     const Axis az = axis_nodes(a.coords_t[n * 3], a.lz), ay = axis_nodes(a.coords_t[n * 3 + 1], a.ly),
@@ -403,6 +455,65 @@ __global__ __launch_bounds__(256) void k_lat_reduce(LatRedArgs a) {
     if (c0 + cc < a.C) {
       const int o = nd * 64 + cc;
       a.dlatents[(s * a.C + c0 + cc) * G + nd] = acc[o] + acc[G * 64 + o] + acc[2 * G * 64 + o] + acc[3 * G * 64 + o];
+    }
+  }
+}
+
+// Same reduction for a compile-time grid (the reference's 3x3x3 default, and 1x1x1): every lane owns one channel and
+// keeps ALL G node sums in registers; the per-sample weights are expanded to dense per-axis vectors so that the
+// accumulator index is static (G FMAs per sample, no LDS traffic in the loop).
+template <int LX, int LY, int LZ>
+__device__ __forceinline__ void dense_axis(const Axis &a, float (&w)[LX > LY ? (LX > LZ ? LX : LZ) : (LY > LZ ? LY : LZ)], int L) {
+#pragma unroll
+  for (int i = 0; i < (LX > LY ? (LX > LZ ? LX : LZ) : (LY > LZ ? LY : LZ)); ++i)
+    w[i] = i < L ? ((i == a.i0 ? a.w0 : 0.f) + ((i == a.i1 && a.i1 != a.i0) ? a.w1 : 0.f)) : 0.f;
+}
+
+#define LATRED_WAVES 8
+template <int LX, int LY, int LZ>
+__global__ __launch_bounds__(64 * LATRED_WAVES) void k_lat_reduce_dense(LatRedArgs a) {
+  constexpr int G = LX * LY * LZ;
+  constexpr int LM = LX > LY ? (LX > LZ ? LX : LZ) : (LY > LZ ? LY : LZ);
+  __shared__ float part[LATRED_WAVES][G][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long s = blockIdx.x;
+  const int c0 = blockIdx.y * 64, c = c0 + lane;
+  const int beg = a.offsets[s], end = a.offsets[s + 1];
+  float acc[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) acc[k] = 0.f;
+  // no store inside the loop: the unrolled iterations' dependent loads (perm -> coords, dlat) overlap
+#pragma unroll 4
+  for (int p = beg + wave; p < end; p += LATRED_WAVES) {
+    const long n = a.perm[p];
+    const Axis az = axis_nodes(a.coords_t[n * 3], LZ), ay = axis_nodes(a.coords_t[n * 3 + 1], LY),
+               ax = axis_nodes(a.coords_t[n * 3 + 2], LX);
+    const float v = c < a.C ? a.dlat[n * a.LP + c] : 0.f;
+    float wx[LM], wy[LM], wz[LM];
+    dense_axis<LX, LY, LZ>(ax, wx, LX);
+    dense_axis<LX, LY, LZ>(ay, wy, LY);
+    dense_axis<LX, LY, LZ>(az, wz, LZ);
+#pragma unroll
+    for (int ix = 0; ix < LX; ++ix) {
+      const float vx = wx[ix] * v;
+#pragma unroll
+      for (int iy = 0; iy < LY; ++iy) {
+        const float vxy = vx * wy[iy];
+#pragma unroll
+        for (int iz = 0; iz < LZ; ++iz) acc[(ix * LY + iy) * LZ + iz] += vxy * wz[iz];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < G; ++k) part[wave][k][lane] = acc[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * G; e += 64 * LATRED_WAVES) {
+    const int cc = e / G, nd = e - cc * G;
+    if (c0 + cc < a.C) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LATRED_WAVES; ++w) t += part[w][nd][cc];
+      a.dlatents[(s * a.C + c0 + cc) * G + nd] = t;
     }
   }
 }
@@ -465,26 +576,38 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
     hipLaunchKernelGGL(k_trilerp_bwd_coord, dim3(grid), dim3(256), 0, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
-  if (dembed != nullptr) {
-    CINEMA_REQUIRE(embed != nullptr, "dembed requested but embed is null");
-    CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
-    hipLaunchKernelGGL(k_affine_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, idx, embed, tf_dim,
-                       embed_per_sample, dcoords_t, (long)N, (long)S, dembed);
-    CINEMA_CHECK_HIP(hipGetLastError());
-  }
-  if (dlatents != nullptr) {
-    int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
+  const bool table_tf = dembed != nullptr && !embed_per_sample;
+  int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
+  if (dlatents != nullptr || table_tf) {
+    CINEMA_REQUIRE(work != nullptr, "cinema_affine_trilerp_bwd: work buffer required");
     CINEMA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)S, s));
-    const unsigned g1 = (unsigned)std::min<long>((N + 255) / 256, 1024);
+    const unsigned g1 = (unsigned)std::min<long>((N + 1023) / 1024, 512);
     hipLaunchKernelGGL(k_hist, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, counts);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, (long)S, offsets);
     hipLaunchKernelGGL(k_fill, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, offsets, counts, perm);
     CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  if (dembed != nullptr) {
+    CINEMA_REQUIRE(embed != nullptr, "dembed requested but embed is null");
+    CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+    float *per_sample_out = table_tf ? reinterpret_cast<float *>(work + 2 * S + 2 + N) : dembed;
+    hipLaunchKernelGGL(k_affine_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, idx, embed, tf_dim,
+                       embed_per_sample, dcoords_t, (long)N, (long)S, per_sample_out);
+    if (table_tf)
+      hipLaunchKernelGGL(k_tf_reduce, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, s, offsets, perm, per_sample_out, tf_dim,
+                         (long)S, dembed);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  if (dlatents != nullptr) {
     const int smem = 4 * G * 64 * (int)sizeof(float);
     CINEMA_REQUIRE(smem <= 64 * 1024, "latent grid of %d nodes too large for the LDS reduction (max 64)", G);
     CINEMA_REQUIRE(S <= 0x7fffffff && (C + 63) / 64 <= 65535, "grid too large");
     LatRedArgs a = {offsets, perm, coords_t, dlat, C, lx, ly, lz, LP, dlatents};
-    hipLaunchKernelGGL(k_lat_reduce, dim3((unsigned)S, (C + 63) / 64), dim3(256), smem, s, a);
+    const dim3 grid((unsigned)S, (C + 63) / 64);
+    if (lx == 3 && ly == 3 && lz == 3) hipLaunchKernelGGL((k_lat_reduce_dense<3, 3, 3>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
+    else if (lx == 1 && ly == 1 && lz == 1) hipLaunchKernelGGL((k_lat_reduce_dense<1, 1, 1>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
+    else if (lx == 2 && ly == 2 && lz == 2) hipLaunchKernelGGL((k_lat_reduce_dense<2, 2, 2>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
+    else hipLaunchKernelGGL(k_lat_reduce, grid, dim3(256), smem, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   return 0;

@@ -206,7 +206,7 @@ def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: t
     """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents_shape
-    need = 2 * S + 2 + n
+    need = 2 * S + 2 + 13 * n   # counts, offsets, perm, per-sample embedding gradients (fp32 x 12)
     if st.work is None or st.work.numel() < need:
         st.work = torch.empty(need, device=eng.device, dtype=torch.int32)
     dlatents = None

@@ -22,10 +22,9 @@ def _as_f32(t: torch.Tensor, device) -> torch.Tensor:
 
 
 def _maybe_pack(state: DecoderState, params):
-    sig = tuple(p._version for p in params) + (state.engine.flat.data_ptr(),)
-    if sig != state.pack_sig:
-        state.engine.pack()
-        state.pack_sig = sig
+    """Refresh the packed bf16/f32 weight copies.  Always: optimisers that write through raw pointers
+    (HipAdamW) do not bump tensor version counters, and one pack launch costs ~25 us."""
+    state.engine.pack()
 
 
 class DecoderFunction(torch.autograd.Function):

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import engine as E
 from .models.inr_decoder import INR_Decoder
+from .optim import HipAdamW
 
 
 class SubjectStore:
@@ -106,9 +107,8 @@ class HotPathTrainer:
             groups.append({"params": [self.tfs], "lr": o["lr_tf"], "weight_decay": o["tf_weight_decay"]})
         if self.cond_param is not None:
             groups.append({"params": [self.cond_param], "lr": o["lr_latent"], "weight_decay": o["latent_weight_decay"]})
-        self.opt_local = torch.optim.AdamW(groups, fused=True)
-        self.opt_mlp = (torch.optim.AdamW([{"params": [self.flat_param], "lr": o["lr_inr"],
-                                            "weight_decay": o["inr_weight_decay"]}], fused=True)
+        self.opt_local = HipAdamW(groups)
+        self.opt_mlp = (HipAdamW([{"params": [self.flat_param], "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}])
                         if self.train_mlp else None)
         self.schedulers = []
         if o.get("scheduler", {}).get("type") == "cosine":
@@ -146,8 +146,6 @@ class HotPathTrainer:
         if self.train_mlp and self.world > 1:
             work = dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         want_tf = self.tfs.requires_grad
-        if want_tf:
-            self.tf_grad.zero_()
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
                                     want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,

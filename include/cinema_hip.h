@@ -135,9 +135,9 @@ int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx, const flo
  *   dlat [Npad x LP] fp32, dcoords_t [Npad x 3] fp32 (gradient reaching the registered
  *   coordinates through the SIREN's first layer; the interpolation term is added here),
  *   -> dlatents (S, C, G) fp32 (overwritten, deterministic per-subject reduction),
- *      dembed: per-sample [N x tf_dim] (affine_per_sample) or table [S x tf_dim] (atomics;
- *      caller zeroes), may be NULL,  dcond [N x cond_dims] or NULL.
- *   work: int32 scratch of at least 2*S + 2 + N entries. */
+ *      dembed: per-sample [N x tf_dim] (embed_per_sample) or table [S x tf_dim] (overwritten;
+ *      per-subject sum in a fixed-shape reduction), may be NULL,  dcond [N x cond_dims] or NULL.
+ *   work: 4-byte scratch of at least 2*S + 2 + 13*N entries. */
 int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
                               int32_t embed_per_sample, const float *affine, const float *shadow,
                               const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
@@ -172,6 +172,24 @@ int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int6
 int cinema_infer_minmax(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, float *minmax, void *stream);
 int cinema_infer_finish(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax,
                         float *vol, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * Optimiser step: torch.optim.AdamW exactly as the reference configures it
+ * (build_atlas.py:432-453: one group per parameter table, decoupled weight decay, no amsgrad),
+ * all groups in one launch.  `step` is the 1-based step count of the group (bias correction).
+ * ------------------------------------------------------------------------------------- */
+#define CINEMA_ADAMW_MAX_GROUPS 8
+typedef struct cinema_adamw_group {
+  float *p;        /* parameters (updated in place) */
+  const float *g;  /* gradients */
+  float *m;        /* exp_avg */
+  float *v;        /* exp_avg_sq */
+  int64_t n;       /* elements */
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;
+} cinema_adamw_group;
+
+int cinema_adamw_step(const cinema_adamw_group *groups /* host */, int32_t n_groups, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,161 @@
+"""GPU tests of the training loop pieces above the decoder: fused AdamW, the autograd-free trainer
+step (pack -> K1 -> SIREN -> K3 with volume sampling -> backward -> optimiser) and label sampling."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def base_args(latent_dim, hidden, layers, mod, out_dim, cond, precision, loss_metric="mse", tf_weight=0.0, cw="default"):
+    ncls = out_dim[-1]
+    return {
+        "inr_decoder": {"in_dim": 3, "out_dim": out_dim, "latent_dim": latent_dim, "cond_dims": cond, "hidden_size": hidden,
+                        "num_hidden_layers": layers, "modulated_layers": mod, "omega": [30, 30], "cnn_kernel_size": 0,
+                        "tf_dim": 6, "precision": precision},
+        "optimizer": {"tf_weight": tf_weight, "loss_metric": loss_metric, "seg_weight": 1.0, "lr_inr": 1e-4,
+                      "inr_weight_decay": 0.0, "lr_latent": 5e-4, "latent_weight_decay": 0.0, "lr_tf": 7.5e-3,
+                      "tf_weight_decay": 0.0, "scheduler": {"type": "cosine", "eta_min": 2.5e-5}},
+        "dataset": {"class_weights": ([0.0] + [1.0] * (ncls - 1)) if cw == "default" else cw, "world_bbox": [155, 155, 155],
+                    "label_names": []},
+        "epochs": {"train": 5, "val": 5}, "mask_reconstruction": False, "device": DEV,
+    }
+
+
+def test_hip_adamw_matches_torch_adamw():
+    from cinema_amd.optim import HipAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000003,), (37, 6), (5, 16, 3, 3, 3)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    a = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    b = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    lrs, wds = [1e-3, 7.5e-3, 5e-4], [0.0, 0.01, 0.1]
+    oa = HipAdamW([{"params": [p], "lr": lr, "weight_decay": wd} for p, lr, wd in zip(a, lrs, wds)])
+    ob = torch.optim.AdamW([{"params": [p], "lr": lr, "weight_decay": wd} for p, lr, wd in zip(b, lrs, wds)])
+    sa = torch.optim.lr_scheduler.CosineAnnealingLR(oa, T_max=4, eta_min=1e-5)
+    sb = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=4, eta_min=1e-5)
+    for it in range(6):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).to(DEV) * (0.1 + it)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for pa, pb in zip(a, b):
+        assert rel_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-6
+
+
+def test_g7_adamw_trajectory_golden():
+    """10 optimisation steps with the reference's three parameter groups + cosine schedule
+    (build_atlas.py:432-459): drop-in modules in fp32 mode + HipAdamW against the reference's trajectory."""
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.optim import HipAdamW
+    from cinema_amd.utils import Criterion
+    g = load_golden("g7_adamw.npz")
+    args = base_args([8, 2, 2, 2], 32, 2, [1], [1, 4], 0, "fp32", loss_metric="l1")
+    dec = INR_Decoder(args, DEV).to(DEV)
+    dec.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("p_")})
+    crit = Criterion(args)
+    lat = torch.nn.Parameter(T(g["lat0"]).to(DEV))
+    tft = torch.nn.Parameter(T(g["tft0"]).to(DEV))
+    coords, idx, target = T(g["coords"]).to(DEV), T(g["idx"]).to(DEV), T(g["target"]).to(DEV)
+    dec(coords, lat, torch.zeros(40, 0, device=DEV), tft[idx], idcs_df=idx)   # re-homes the parameters before the optimiser sees them
+    opt = HipAdamW([{"params": [lat], "lr": 5e-4, "weight_decay": 0.0}, {"params": [tft], "lr": 7.5e-3, "weight_decay": 0.0},
+                    {"params": list(dec.parameters()), "lr": 1e-4, "weight_decay": 0.0}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=5, eta_min=2.5e-5)
+    losses = []
+    for step in range(10):
+        opt.zero_grad()
+        tfs = tft[idx]
+        out = dec(coords, lat, torch.zeros(40, 0, device=DEV), tfs, idcs_df=idx)
+        loss = crit(out, target, tfs, seg_weight=1.0)
+        loss["total"].backward()
+        for p in [lat, tft] + list(dec.parameters()):
+            p.grad = p.grad.contiguous()
+        opt.step()
+        losses.append(float(loss["total"]))
+        if step % 2 == 1:
+            sched.step()
+    assert np.allclose(losses, g["losses"], rtol=2e-4), (losses, g["losses"].tolist())
+    # Adam normalises the update, so tiny gradient differences flip early steps of near-zero-gradient entries:
+    # compare the trajectories in units of the total distance travelled
+    for name, p, ref0, ref in (("lat", lat, g["lat0"], g["lat10"]), ("tft", tft, g["tft0"], g["tft10"])):
+        move = np.abs(ref - ref0).max()
+        assert np.abs(p.detach().cpu().numpy() - ref).max() < 2e-2 * move, name
+    for n, p in dec.named_parameters():
+        move = np.abs(g["q_" + n] - g["p_" + n]).max()
+        assert np.abs(p.detach().cpu().numpy() - g["q_" + n]).max() < 2e-2 * max(move, 1e-12), n
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_trainer_step_matches_oracle(precision):
+    """The autograd-free step: gradients it leaves behind == CPU oracle on the same samples (targets gathered from
+    the resident volumes: labels bit-exact), and the parameters move as torch.optim.AdamW would move them."""
+    from oracle import cinema_oracle as O
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
+    torch.manual_seed(21)
+    store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1))
+    tr = HotPathTrainer(args, store, DEV)
+    with torch.no_grad():
+        tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+    n = 700
+    lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()
+    coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
+    base = subj.long() * store.V + voxel
+    target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
+    lat_o, tf_o = lat0.clone().requires_grad_(True), tf0.clone().requires_grad_(True)
+    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse",
+               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0)
+    loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, None, cfg)
+    # K3 sampled exactly these targets (bit-exact labels and intensities)
+    tgt_dev = torch.empty(n, 3, device=DEV)
+    tr.step(0, n)
+    from cinema_amd import engine as E
+    sums = torch.zeros(4, device=DEV)
+    dout = torch.empty(E.round_up(n, 128), 12, device=DEV)
+    E.sample_loss(None, tr.eng.ws.out, n, 2, 10, "mse", tr.class_w, 1.0, 1.0, dout, sums, voxel=store.voxel[:n],
+                  subj=store.subj[:n], intens=store.intens, labels=store.labels, voxels_per_subject=store.V, target_out=tgt_dev)
+    assert torch.equal(tgt_dev.cpu(), target)
+    got = tr.loss_dict()
+    assert abs(got["total"] - float(loss_o["total"])) < tol * abs(float(loss_o["total"]))
+    errs = {"glat": rel_err(tr.lat_grad.cpu().numpy(), lat_o.grad.numpy()),
+            "gtf": rel_err(tr.tf_grad.cpu().numpy(), tf_o.grad.numpy())}
+    gviews = tr.eng.param_views(tr.eng.flat_grad.cpu())
+    for k, p in params.items():
+        errs["g_" + k] = rel_err(gviews[k].numpy(), p.grad.numpy())
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+    # one AdamW step from the trainer's own gradients
+    ref_p = [torch.nn.Parameter(lat0.clone()), torch.nn.Parameter(tf0.clone()), torch.nn.Parameter(flat0.clone())]
+    ref_p[0].grad, ref_p[1].grad, ref_p[2].grad = tr.lat_grad.cpu(), tr.tf_grad.cpu(), tr.eng.flat_grad.cpu()
+    ref_opt = torch.optim.AdamW([{"params": [ref_p[0]], "lr": 5e-4, "weight_decay": 0.0},
+                                 {"params": [ref_p[1]], "lr": 7.5e-3, "weight_decay": 0.0},
+                                 {"params": [ref_p[2]], "lr": 1e-4, "weight_decay": 0.0}])
+    ref_opt.step()
+    assert rel_err(tr.latents.detach().cpu().numpy(), ref_p[0].detach().numpy()) < 1e-5
+    assert rel_err(tr.tfs.detach().cpu().numpy(), ref_p[1].detach().numpy()) < 1e-5
+    assert rel_err(tr.eng.flat.detach().cpu().numpy(), ref_p[2].detach().numpy()) < 1e-5
+
+
+def test_trainer_loss_decreases_over_an_epoch_slice():
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([32, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, "bf16")
+    torch.manual_seed(2)
+    store = SubjectStore.synthetic(4, (32, 32, 32), 155.0 / 32, [155, 155, 155], 2, 10, seed=3, device=DEV)
+    tr = HotPathTrainer(args, store, DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(4))
+    n = 2000
+    first = last = None
+    for i in range(60):
+        lo = (i * n) % (len(store) - n)
+        tr.step(lo, lo + n)
+        if i == 0:
+            first = tr.loss_dict()["total"]
+    last = tr.loss_dict()["total"]
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
