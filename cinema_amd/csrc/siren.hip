@@ -101,7 +101,7 @@ struct FwdArgs {
   const void *Wls; const void *Wlt;                           // packed [HP x LP] T
   const float *bias_l;                                        // [2H]
   void *Y; void *C; void *Z; void *S; int ldo; int HP;        // outputs [Npad x HP] T
-  int H; float omega; int tiles_f;
+  int H; float omega; int tiles_f; int dbg;
 };
 
 template <typename T, bool MOD, bool SMALLK>
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_layer_fwd(FwdArgs a) {
   if constexpr (SMALLK) {
     smallk_accumulate(accZ, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.H);
   } else {
-    nt_mainloop<T>(accZ, (const T *)a.W + (size_t)c.f0 * a.K, a.K, a.rowsW - c.f0, (const T *)a.X + (size_t)c.n0 * a.ldx,
+    if (!(a.dbg & 1)) nt_mainloop<T>(accZ, (const T *)a.W + (size_t)c.f0 * a.K, a.K, a.rowsW - c.f0, (const T *)a.X + (size_t)c.n0 * a.ldx,
                    a.ldx, a.K, smem);
   }
   const bool fvalid = c.fb < a.HP;
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_layer_fwd(FwdArgs a) {
     for (int j = 0; j < 16; ++j) {
       float ph = accZ[j >> 2][st][j & 3];
       if constexpr (!MOD) ph *= a.omega;
-      sincos_t<T>(ph, yv[j], cv[j]);
+      if (a.dbg & 2) { yv[j] = ph; cv[j] = ph; } else sincos_t<T>(ph, yv[j], cv[j]);
     }
-    if (fvalid) {
+    if (fvalid && !(a.dbg & 4)) {
       store16((T *)a.Y + (size_t)c.nrow[st] * a.ldo + c.fb, yv);
       store16((T *)a.C + (size_t)c.nrow[st] * a.ldo + c.fb, cv);
     }
@@ -656,7 +656,7 @@ static int forward_impl(const cinema_siren_desc *d, const float *params, const v
     a.omega = i == 0 ? d->omega_first : d->omega_hidden;
     a.Y = sv + slot * d->sv_y[i];
     a.C = sv + slot * d->sv_c[i];
-    a.rowsW = HP;
+    a.rowsW = HP; { const char *e = getenv("CINEMA_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (mod) {
       a.LAT = lat; a.LP = LP;
       a.Wls = pk + d->pk_wls[i];

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc counter_collection.csv per kernel (averages over dispatches)."""
+import csv, collections, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True)[0]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")
+    if not any(k in n for k in ("k_layer", "k_dw", "k_dlat", "k_final", "k_lat_reduce", "k_trilerp", "k_pack", "k_adamw")):
+        continue
+    agg[n[:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for n, c in agg.items():
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    print(f"{n:64s} " + " ".join(f"{k}={v:.4g}" for k, v in sorted(m.items())))
