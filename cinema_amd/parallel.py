@@ -1,0 +1,94 @@
+"""Multi-GPU plumbing of the hot path: one process per GPU, subjects sharded, MLP replicated.
+
+The reference is single-device.  Its data-parallel restatement: a subject -- latent grid, rigid/affine
+row, resident volumes, foreground list, AdamW moments -- lives on exactly ONE rank; every rank runs the reference's
+step (build_atlas.py:69-90) on `n_samples` coordinates of ITS subjects; the only data-path exchange is one
+all-reduce(average) of the flat SIREN gradient per step.  Everything here is backend-agnostic (RCCL on the GPUs,
+gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(process_group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(process_group), dist.get_world_size(process_group)
+    return 0, 1
+
+
+def shard_subjects(n_subjects: int, rank: int, world: int) -> List[int]:
+    """Dataframe rows owned by `rank`: a balanced contiguous block (sizes differ by at most one), so that a
+    checkpoint's latent / transformation tables are the rank-order concatenation of the shards."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(n_subjects, world)
+    lo = rank * base + min(rank, rem)
+    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+def owner_of(subject: int, n_subjects: int, world: int) -> int:
+    base, rem = divmod(n_subjects, world)
+    edge = rem * (base + 1)
+    return subject // (base + 1) if subject < edge else rem + (subject - edge) // max(base, 1)
+
+
+def agree_steps(local_steps: int, process_group=None, device="cpu") -> int:
+    """Steps per epoch every rank will run (the minimum over ranks: a rank whose foreground list is longer drops
+    its tail for this epoch; the list is reshuffled every epoch so no voxel is excluded systematically).
+    Without it a rank with more steps would wait forever in the gradient all-reduce."""
+    _, world = world_info(process_group)
+    if world == 1:
+        return local_steps
+    t = torch.tensor([local_steps], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+    return int(t.item())
+
+
+def allreduce_mean_(flat_grad: torch.Tensor, process_group=None, async_op: bool = False):
+    """Average the replicated MLP's flat gradient over ranks in place.  With equal per-rank sample counts and a
+    mean-reduced loss this is the gradient of the same loss on the union batch (tests/test_dp_gloo.py).  RCCL has a
+    native AVG; gloo has not, so sum and scale there."""
+    _, world = world_info(process_group)
+    if world == 1:
+        return None
+    backend = dist.get_backend(process_group)
+    if backend == "nccl":
+        return dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=process_group, async_op=async_op)
+    work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=False)
+    flat_grad.div_(world)
+    return None
+
+
+def broadcast_(tensor: torch.Tensor, src: int = 0, process_group=None):
+    """Make the replicated parameters identical at start-up (each rank seeds its own latents but must share the MLP)."""
+    _, world = world_info(process_group)
+    if world > 1:
+        dist.broadcast(tensor, src=src, group=process_group)
+    return tensor
+
+
+def gather_rows(local: torch.Tensor, process_group=None) -> torch.Tensor:
+    """Concatenate per-rank tables of different lengths in rank order (latents / transformations for a checkpoint,
+    condition values for the atlas weights).  Every rank gets the full table."""
+    rank, world = world_info(process_group)
+    if world == 1:
+        return local
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=process_group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = local.new_zeros((m, *local.shape[1:]))
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=process_group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def shard_jobs(n_jobs: int, rank: int, world: int) -> List[int]:
+    """Round-robin split of independent jobs ((time point x condition) atlas volumes) over ranks."""
+    return list(range(rank, n_jobs, world))

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import parallel as par
 from .models.inr_decoder import INR_Decoder
 from .optim import HipAdamW
 
@@ -77,7 +78,7 @@ class HotPathTrainer:
         import torch.distributed as dist
         self.args, self.store, self.device, self.split = args, store, torch.device(device), split
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank, self.world = par.world_info(process_group)
         a, o = args["inr_decoder"], args["optimizer"]
         self.sr_dims = sum(a["out_dim"][:-1])
         self.n_cls = a["out_dim"][-1]
@@ -85,6 +86,7 @@ class HotPathTrainer:
         self.decoder = decoder if decoder is not None else INR_Decoder(args, str(self.device)).to(self.device)
         self.state = self.decoder.sr_net.hot_state(self.device)
         self.eng = self.state.engine
+        par.broadcast_(self.eng.flat, 0, process_group)        # replicas start from rank 0's initialisation
         self.k1 = self.state.k1
         S = store.n_subjects
         tf_w = max(a["tf_dim"], 6)
@@ -144,7 +146,7 @@ class HotPathTrainer:
         eng.backward(n, ws.dout, weight_grads=self.train_mlp)
         work = None
         if self.train_mlp and self.world > 1:
-            work = dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
         want_tf = self.tfs.requires_grad
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
@@ -180,12 +182,14 @@ class HotPathTrainer:
         """One pass over the shuffled foreground list in chunks of n_samples (build_atlas.py:65-68)."""
         self.store.shuffle(generator)
         m = len(self.store)
+        total = (m + n_samples - 1) // n_samples
+        if max_steps is not None:
+            total = min(total, max_steps)
+        total = par.agree_steps(total, self.pg, self.device)   # every rank must join every gradient all-reduce
         steps = 0
-        for lo in range(0, m, n_samples):
+        for lo in range(0, total * n_samples, n_samples):
             self.step(lo, min(lo + n_samples, m))
             steps += 1
-            if max_steps is not None and steps >= max_steps:
-                break
         for s in self.schedulers:
             s.step()
         return steps
