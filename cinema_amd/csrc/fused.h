@@ -1,0 +1,20 @@
+// Activation-stationary ("fused") SIREN kernels, bf16 only: internal interface between fused.hip and siren.hip.
+#pragma once
+#include "common.h"
+
+// Weight streams (cinema_siren_desc::pk_fs / pk_bs): the MFMA A fragments of every GEMM of the stack, in the exact
+// order one wave consumes them, so that a wave's weight traffic is ONE contiguous, fully coalesced stream:
+//   [slab = 64 output features][k32 step][fragment ft = 0..3][lane = 0..63][8 x bf16]
+// lane (i = lane & 15, gk = lane >> 4) of fragment ft holds W[slab*64 + 16*(i>>2) + 4*ft + (i&3)][32*step + 8*gk + 0..7],
+// which makes accumulator register r of fragment ft in lane (i, g) the output feature slab*64 + 16*g + 4*ft + r of
+// sample i: 16 consecutive features per lane, as in gemm_engine.h.
+#define FUSED_STEP_ELEMS 2048     // bf16 elements per k32 step of one slab (4 KB)
+#define FUSED_RING 4              // steps a wave keeps in flight
+#define FUSED_MAX_HP 512          // 8 waves x 64 features
+#define FUSED_TS 64               // samples per workgroup
+
+bool fused_eligible(const cinema_siren_desc *d);
+void fused_plan(cinema_siren_desc *d, long *pk);                   // appends the stream regions to the packed layout
+int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s);
+int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
+                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s);

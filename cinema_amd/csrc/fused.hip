@@ -1,0 +1,418 @@
+// Activation-stationary SIREN forward for gfx950 (bf16 MFMA, fp32 accumulate).
+// Reference arithmetic: models/siren.py:26-36 (SineLayer.forward), :59-61 (Siren.forward).
+//
+// One workgroup = 8 waves owns FUSED_TS = 64 samples for the WHOLE stack.  The layer input x [64 x HP] and the
+// interpolated latent rows [64 x LP] live in LDS for the lifetime of the workgroup, so activations are never
+// re-read from HBM between layers; the saved tensors the backward needs (y, c, and z, s of modulated layers)
+// are streamed out once.  Wave w owns output features [64w, 64w+64) of every layer: its MFMA A fragments come
+// straight from global memory (L2) through a register ring fed by one contiguous per-wave weight stream
+// (fused.h), its B fragments are conflict-free ds_read_b128 from the shared x / lat tiles.
+#include "fused.h"
+#include "gemm_engine.h"
+#include <algorithm>
+
+namespace {
+
+inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+
+// ----------------------------------------------------------------------------------------
+// stream plans (host)
+// ----------------------------------------------------------------------------------------
+struct Seg { long src; int ld, rows, cols, transpose, nsteps, step0, pad_; };
+#define FUSED_MAX_SEGS 64
+struct StreamPlan { Seg seg[FUSED_MAX_SEGS]; int nseg, steps; };
+
+void plan_add(StreamPlan &p, long src, int ld, int rows, int cols, int tr, int nsteps) {
+  Seg s = {src, ld, rows, cols, tr, nsteps, p.steps, 0};
+  p.seg[p.nseg++] = s;
+  p.steps += nsteps;
+}
+
+// forward: per layer [s = Wl_scale lat] [z = W x (i > 0)] [t = Wl_shift lat]
+void plan_fwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
+  const int H = d->hidden, L = d->lat;
+  p.nseg = 0; p.steps = 0;
+  for (int i = 0; i < d->n_layers; ++i) {
+    const bool mod = (d->modulated_mask >> i) & 1u;
+    if (mod) plan_add(p, d->off_wl[i], L, H, L, 0, d->LP / 32);
+    if (i > 0) plan_add(p, d->off_w[i], H, H, H, 0, d->HP / 32);
+    if (mod) plan_add(p, d->off_wl[i] + (long)H * L, L, H, L, 0, d->LP / 32);
+  }
+}
+
+// backward chain: dy_i = W_{i+1}^T dz_{i+1}, i = n_layers-2 .. 0
+void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
+  const int H = d->hidden;
+  p.nseg = 0; p.steps = 0;
+  for (int i = d->n_layers - 2; i >= 0; --i) plan_add(p, d->off_w[i + 1], H, H, H, 1, d->HP / 32);
+}
+
+struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg, steps, nslab; const float *params; bf16_t *dst; };
+
+__global__ void k_pack_stream(PackStreamArgs a) {
+  const long nchunk = (long)a.nslab * a.steps * 256;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(q & 63), ft = (int)((q >> 6) & 3);
+    const long sq = q >> 8;
+    const int step = (int)(sq % a.steps), slab = (int)(sq / a.steps);
+    int si = 0;
+    while (si + 1 < a.nseg && step >= a.seg[si + 1].step0) ++si;
+    const Seg sg = a.seg[si];
+    const int kk = step - sg.step0, i = lane & 15, gk = lane >> 4;
+    const int feat = slab * 64 + 16 * (i >> 2) + 4 * ft + (i & 3);
+    const int k0 = 32 * kk + 8 * gk;
+    const float *src = a.params + sg.src;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float x = 0.f;
+      if (feat < sg.rows && k < sg.cols) x = sg.transpose ? src[(long)k * sg.ld + feat] : src[(long)feat * sg.ld + k];
+      v[j] = (bf16_t)x;
+    }
+    *reinterpret_cast<bf16x8 *>(a.dst + q * 8) = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// device: weight ring + segment runner
+// ----------------------------------------------------------------------------------------
+// Addresses are kept as wave-uniform 64-bit bases (SGPRs) + 32-bit per-lane byte offsets so that the only VGPRs
+// alive across the layer loop are the accumulators, the ring and a handful of offsets.
+struct WRing {
+  bf16x8 s[FUSED_RING][4];
+  const char *wp;  // uniform: next step to fetch
+};
+
+__device__ __forceinline__ void ring_fetch(bf16x8 (&slot)[4], const char *p, unsigned lane16) {
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) slot[ft] = *reinterpret_cast<const bf16x8 *>(p + ft * 1024 + lane16);
+}
+
+__device__ __forceinline__ void ring_init(WRing &r, const char *stream, unsigned lane16) {
+#pragma unroll
+  for (int k = 0; k < FUSED_RING; ++k) ring_fetch(r.s[k], stream + k * 4096, lane16);
+  r.wp = stream + FUSED_RING * 4096;
+}
+
+// 16-byte chunk c of row `row` of an LDS tile sits at chunk position c ^ (row & 15) (rows are multiples of 256 B):
+// the 16 lanes of every ds_read_b128 lane group then cover all 64 banks exactly once.
+#define FUSED_STEP(SLOT, KSTEP)                                                                              \
+  {                                                                                                          \
+    const int off_ = ((((KSTEP) << 2) + gk) ^ i) << 4;                                                       \
+    bf16x8 b_[4];                                                                                            \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                         \
+      b_[st] = *(const LDS_AS bf16x8 *)(tile + rowoff + st * 16 * rowbytes + off_);                          \
+    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                         \
+      _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                       \
+        acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
+    ring_fetch(r.s[SLOT], r.wp, lane16);                                                                     \
+    r.wp += 4096;                                                                                            \
+  }
+
+// acc[f][n] += sum_k A_stream[f][k] * tile[n][k] over nsteps (even) k32 steps of the wave's weight stream.
+// Ring slots are addressed statically (a run-time slot parity makes hipcc keep every slot twice and spill): slot 0
+// always holds the next step at segment boundaries; a segment of 4m+2 steps ends by renaming slots 2,3 -> 0,1.
+__device__ __forceinline__ void run_seg(f32x4 (&acc)[4][4], WRing &r, const lds_char *tile, int rowbytes, int nsteps,
+                                        int i, int gk, unsigned lane16) {
+  const int rowoff = i * rowbytes;
+  int k = 0;
+  for (; k + 4 <= nsteps; k += 4) {
+    FUSED_STEP(0, k) FUSED_STEP(1, k + 1) FUSED_STEP(2, k + 2) FUSED_STEP(3, k + 3)
+  }
+  if (k < nsteps) {
+#define FUSED_TAIL(SLOT, KSTEP)                                                                              \
+  {                                                                                                          \
+    const int off_ = ((((KSTEP) << 2) + gk) ^ i) << 4;                                                       \
+    bf16x8 b_[4];                                                                                            \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                         \
+      b_[st] = *(const LDS_AS bf16x8 *)(tile + rowoff + st * 16 * rowbytes + off_);                          \
+    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                         \
+      _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                       \
+        acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
+    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft) r.s[SLOT][ft] = r.s[SLOT + 2][ft];                      \
+    ring_fetch(r.s[SLOT + 2], r.wp, lane16);                                                                 \
+    r.wp += 4096;                                                                                            \
+  }
+    FUSED_TAIL(0, k) FUSED_TAIL(1, k + 1)
+#undef FUSED_TAIL
+  }
+}
+static_assert(FUSED_RING == 4, "run_seg is written for a 4-step ring");
+
+__device__ __forceinline__ void fill_acc(f32x4 (&acc)[4][4], const f32x4 (&v)[4]) {
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) acc[ft][st] = v[ft];
+}
+
+// v[q] = p[fb + 4q .. +3] (fb, limit multiples of 16: the 16 features of a lane are all valid or all padding)
+__device__ __forceinline__ void feature_vec(const float *p, unsigned fb, int limit, f32x4 (&v)[4]) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool ok = (int)fb < limit;
+  const char *pc = (const char *)p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = ok ? *reinterpret_cast<const f32x4 *>(pc + (fb * 4u + q * 16u)) : zero;
+}
+
+__device__ __forceinline__ void pack16(const float (&v)[16], bf16x8 &lo, bf16x8 &hi) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { lo[j] = (bf16_t)v[j]; hi[j] = (bf16_t)v[8 + j]; }
+}
+
+// ----------------------------------------------------------------------------------------
+// fused forward
+// ----------------------------------------------------------------------------------------
+struct FusedFwdArgs {
+  const bf16_t *stream; long slab_elems;
+  const float *params;
+  long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0;
+  unsigned mod_mask; int n_layers, in_dim, H, HP, LP, out_dim;
+  float om_first, om_hidden;
+  const float *coords_t; const bf16_t *lat;
+  bf16_t *saved; long slot;
+  int sv_y[CINEMA_MAX_LAYERS], sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
+  const bf16_t *wf; const float *bf; float *out;
+  int xrow, lrow;
+};
+
+__global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char *xs = (lds_char *)smem;
+  lds_char *ls = xs + FUSED_TS * a.xrow;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
+  const int i = lane & 15, g = lane >> 4, gk = g;
+  const long n0 = (long)blockIdx.x * FUSED_TS;
+  const int slab = wave;
+  const bool active = slab * 64 < a.HP;
+  const unsigned fb = slab * 64 + 16 * g;
+  const unsigned lane16 = lane * 16;
+  // byte offset of (sample i of sample tile 0, feature fb) inside a [64 x HP] bf16 tile; tile st adds st*16*HP*2
+  const unsigned toff = (i * a.HP + fb) * 2u;
+  const unsigned tstep = 16u * a.HP * 2u;
+
+  // latent rows of this tile -> LDS (swizzled 16-B chunks)
+  {
+    const int cpr = a.LP >> 3;  // chunks per row
+    const char *lt = (const char *)(a.lat + n0 * a.LP);
+    for (int q = tid; q < FUSED_TS * cpr; q += 512) {
+      const int row = q / cpr, c = q - row * cpr;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(lt + (unsigned)(row * a.LP + c * 8) * 2u);
+      *(LDS_AS u32x4 *)(ls + row * a.lrow + ((c ^ (row & 15)) << 4)) = v;
+    }
+  }
+  WRing r;
+  if (active) ring_init(r, (const char *)(a.stream + (long)slab * a.slab_elems), lane16);
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma nounroll
+  for (int l = 0; l < a.n_layers; ++l) {
+    const bool mod = (a.mod_mask >> l) & 1u;
+    const float omega = l == 0 ? a.om_first : a.om_hidden;
+    // re-derive the per-lane offsets from opaque copies in every iteration: otherwise LICM hoists ~100 registers of
+    // address arithmetic out of the layer loop and spills them
+    unsigned toff_l = toff, fb_l = fb;
+    int i_l = i;
+    asm volatile("" : "+v"(toff_l), "+v"(fb_l), "+v"(i_l));
+    if (active) {
+      f32x4 v[4];
+      // modulated layer: scale branch first; s is stored (the backward needs it) and kept as packed bf16 --
+      // the phase below uses exactly the value the backward will read
+      bf16x8 sp[4][2];
+      if (mod) {
+        feature_vec(a.params + a.off_bl[l], fb_l, a.H, v);
+        fill_acc(acc, v);
+        run_seg(acc, r, ls, a.lrow, a.LP >> 5, i_l, gk, lane16);
+        char *S = (char *)(a.saved + a.slot * a.sv_s[l] + n0 * a.HP);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          float sv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sv[j] = acc[j >> 2][st][j & 3];
+          pack16(sv, sp[st][0], sp[st][1]);
+          *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep)) = sp[st][0];
+          *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
+        }
+      }
+      feature_vec(a.params + a.off_b[l], fb_l, a.H, v);
+      fill_acc(acc, v);
+      if (l == 0) {
+        // first layer: K = in_dim <= 3 on the VALU in fp32
+        const float *ct = a.coords_t + n0 * a.in_dim;
+        const float *w0 = a.params + a.off_w0;
+        for (int k = 0; k < a.in_dim; ++k) {
+          float xv[4], w[16];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) xv[st] = ct[(unsigned)((16 * st + i_l) * a.in_dim + k)];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) w[j] = ((int)fb_l < a.H) ? w0[(fb_l + j) * (unsigned)a.in_dim + k] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w[j] * xv[st];
+        }
+      } else {
+        run_seg(acc, r, xs, a.xrow, a.HP >> 5, i_l, gk, lane16);
+      }
+      if (mod) {
+        f32x4 bt[4];
+        feature_vec(a.params + a.off_bl[l] + a.H, fb_l, a.H, bt);
+        char *Z = (char *)(a.saved + a.slot * a.sv_z[l] + n0 * a.HP);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          float zv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) zv[j] = acc[j >> 2][st][j & 3];
+          bf16x8 zlo, zhi;
+          pack16(zv, zlo, zhi);
+          *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep)) = zlo;
+          *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep + 16u)) = zhi;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float sj = (float)(j < 8 ? sp[st][0][j & 7] : sp[st][1][j & 7]);
+            acc[j >> 2][st][j & 3] = omega * zv[j] * sj + bt[j >> 2][j & 3];
+          }
+        }
+        run_seg(acc, r, ls, a.lrow, a.LP >> 5, i_l, gk, lane16);
+      }
+    }
+    __syncthreads();  // every wave has finished reading x
+    if (active) {
+      char *Y = (char *)(a.saved + a.slot * a.sv_y[l] + n0 * a.HP);
+      char *C = (char *)(a.saved + a.slot * a.sv_c[l] + n0 * a.HP);
+      const int c0 = fb_l >> 3;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        float yv[16], cv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float ph = acc[j >> 2][st][j & 3];
+          if (!mod) ph *= omega;
+          yv[j] = __sinf(ph);
+          cv[j] = __cosf(ph);
+        }
+        bf16x8 ylo, yhi, clo, chi;
+        pack16(yv, ylo, yhi);
+        pack16(cv, clo, chi);
+        *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep)) = ylo;
+        *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep + 16u)) = yhi;
+        *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep)) = clo;
+        *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep + 16u)) = chi;
+        lds_char *xr = xs + (16 * st + i_l) * a.xrow;
+        *(LDS_AS bf16x8 *)(xr + ((c0 ^ i_l) << 4)) = ylo;
+        *(LDS_AS bf16x8 *)(xr + (((c0 + 1) ^ i_l) << 4)) = yhi;
+      }
+    }
+    __syncthreads();  // x of the next layer is complete
+  }
+
+  // final linear (siren.py:61): out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]; wave w < 4 takes sample tile w
+  if (wave < 4) {
+    const int st = wave, KT = a.HP + a.LP;
+    f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+    const char *wrow = (const char *)a.wf;
+    const unsigned woff = (i * KT + 8 * gk) * 2u;
+    const lds_char *xrp = xs + (16 * st + i) * a.xrow;
+    const lds_char *lrp = ls + (16 * st + i) * a.lrow;
+#pragma unroll 4
+    for (int k = 0; k < (a.HP >> 5); ++k) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wrow + (woff + 64u * k));
+      const bf16x8 b = *(const LDS_AS bf16x8 *)(xrp + ((((k << 2) + gk) ^ i) << 4));
+      o4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, o4, 0, 0, 0);
+    }
+#pragma unroll 2
+    for (int k = 0; k < (a.LP >> 5); ++k) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wrow + (woff + 2u * a.HP + 64u * k));
+      const bf16x8 b = *(const LDS_AS bf16x8 *)(lrp + ((((k << 2) + gk) ^ i) << 4));
+      o4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, o4, 0, 0, 0);
+    }
+    float *ot = a.out + (n0 + 16 * st) * a.out_dim;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int o = 4 * g + rr;
+      if (o < a.out_dim) ot[(unsigned)(i * a.out_dim + o)] = o4[rr] + a.bf[o];
+    }
+  }
+}
+
+}  // namespace
+
+// ========================================================================================
+// host side
+// ========================================================================================
+static int fused_lds_bytes(const cinema_siren_desc *d) {
+  return FUSED_TS * (round_up_i(d->HP * 2, 256) + round_up_i(d->LP * 2, 256));
+}
+
+bool fused_eligible(const cinema_siren_desc *d) {
+  return d->precision == CINEMA_PREC_BF16 && d->HP <= FUSED_MAX_HP && fused_lds_bytes(d) <= 160 * 1024;
+}
+
+void fused_plan(cinema_siren_desc *d, long *pk) {
+  d->pk_fs = d->pk_bs = -1;
+  d->fs_steps = d->bs_steps = 0;
+  if (!fused_eligible(d)) return;
+  StreamPlan p;
+  const long nslab = d->HP / 64;
+  plan_fwd_stream(d, p);
+  d->pk_fs = *pk; d->fs_steps = p.steps;
+  *pk += nslab * p.steps * FUSED_STEP_ELEMS;
+  plan_bwd_stream(d, p);
+  d->pk_bs = *pk; d->bs_steps = p.steps;
+  *pk += nslab * p.steps * FUSED_STEP_ELEMS;
+  *pk += (long)FUSED_RING * FUSED_STEP_ELEMS;  // zero pad: the rings prefetch past the end of the last slab
+}
+
+int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
+  if (d->pk_fs < 0) return 0;
+  for (int which = 0; which < 2; ++which) {
+    StreamPlan p;
+    if (which == 0) plan_fwd_stream(d, p); else plan_bwd_stream(d, p);
+    if (p.steps == 0) continue;
+    PackStreamArgs a;
+    for (int k = 0; k < p.nseg; ++k) a.seg[k] = p.seg[k];
+    a.nseg = p.nseg; a.steps = p.steps; a.nslab = d->HP / 64;
+    a.params = params;
+    a.dst = (bf16_t *)packed + (which == 0 ? d->pk_fs : d->pk_bs);
+    const long nchunk = (long)a.nslab * a.steps * 256;
+    const int grid = (int)std::min<long>((nchunk + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
+                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s) {
+  CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "fused_forward: descriptor not planned for the fused path");
+  CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_forward: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
+  FusedFwdArgs a = {};
+  a.stream = (const bf16_t *)packed + d->pk_fs;
+  a.slab_elems = (long)d->fs_steps * FUSED_STEP_ELEMS;
+  a.params = params;
+  for (int i = 0; i < d->n_layers; ++i) {
+    a.off_b[i] = d->off_b[i]; a.off_bl[i] = d->off_bl[i];
+    a.sv_y[i] = d->sv_y[i]; a.sv_c[i] = d->sv_c[i]; a.sv_z[i] = d->sv_z[i]; a.sv_s[i] = d->sv_s[i];
+  }
+  a.off_w0 = d->off_w[0];
+  a.mod_mask = d->modulated_mask; a.n_layers = d->n_layers; a.in_dim = d->in_dim;
+  a.H = d->hidden; a.HP = d->HP; a.LP = d->LP; a.out_dim = d->out_dim;
+  a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
+  a.coords_t = coords_t; a.lat = (const bf16_t *)lat;
+  a.saved = (bf16_t *)saved; a.slot = (long)Npad * d->HP;
+  a.wf = (const bf16_t *)packed + d->pk_wf; a.bf = params + d->off_bf; a.out = out;
+  a.xrow = round_up_i(d->HP * 2, 256); a.lrow = round_up_i(d->LP * 2, 256);
+  const int smem = fused_lds_bytes(d);
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_smem = smem;
+  }
+  hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(Npad / FUSED_TS)), dim3(512), smem, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  (void)N;
+  return 0;
+}

@@ -1,7 +1,9 @@
 // SIREN stack kernels (forward, backward, weight gradients, packing) for gfx950.
 // Reference arithmetic: models/siren.py:26-36 (SineLayer.forward), :59-61 (Siren.forward).
 #include "gemm_engine.h"
+#include "fused.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -101,7 +103,7 @@ struct FwdArgs {
   const void *Wls; const void *Wlt;                           // packed [HP x LP] T
   const float *bias_l;                                        // [2H]
   void *Y; void *C; void *Z; void *S; int ldo; int HP;        // outputs [Npad x HP] T
-  int H; float omega; int tiles_f; int dbg;
+  int H; float omega; int tiles_f;
 };
 
 template <typename T, bool MOD, bool SMALLK>
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_layer_fwd(FwdArgs a) {
   if constexpr (SMALLK) {
     smallk_accumulate(accZ, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.H);
   } else {
-    if (!(a.dbg & 1)) nt_mainloop<T>(accZ, (const T *)a.W + (size_t)c.f0 * a.K, a.K, a.rowsW - c.f0, (const T *)a.X + (size_t)c.n0 * a.ldx,
+    nt_mainloop<T>(accZ, (const T *)a.W + (size_t)c.f0 * a.K, a.K, a.rowsW - c.f0, (const T *)a.X + (size_t)c.n0 * a.ldx,
                    a.ldx, a.K, smem);
   }
   const bool fvalid = c.fb < a.HP;
@@ -150,9 +152,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_layer_fwd(FwdArgs a) {
     for (int j = 0; j < 16; ++j) {
       float ph = accZ[j >> 2][st][j & 3];
       if constexpr (!MOD) ph *= a.omega;
-      if (a.dbg & 2) { yv[j] = ph; cv[j] = ph; } else sincos_t<T>(ph, yv[j], cv[j]);
+      sincos_t<T>(ph, yv[j], cv[j]);
     }
-    if (fvalid && !(a.dbg & 4)) {
+    if (fvalid) {
       store16((T *)a.Y + (size_t)c.nrow[st] * a.ldo + c.fb, yv);
       store16((T *)a.C + (size_t)c.nrow[st] * a.ldo + c.fb, cv);
     }
@@ -560,6 +562,7 @@ extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
     }
   }
   d->pk_wf = pk; pk += 16L * (HP + LP);
+  fused_plan(d, &pk);
   d->n_params = off;
   d->pk_total = pk;
   d->n_saved = sv;
@@ -617,7 +620,14 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
   dim3 grid2(1, nb);
   hipLaunchKernelGGL((k_pack<T>), grid2, dim3(256), 0, s, b);
   CINEMA_CHECK_HIP(hipGetLastError());
-  return 0;
+  return fused_pack(d, params, packed, s);
+}
+
+// The activation-stationary kernels serve bf16 stacks up to hidden 512; CINEMA_SIREN_LAYERED=1 forces the
+// layer-by-layer kernels (the only path for fp32 and wider stacks) so tests can cover both.
+static bool use_fused(const cinema_siren_desc *d) {
+  static const bool layered = [] { const char *e = getenv("CINEMA_SIREN_LAYERED"); return e && e[0] == '1'; }();
+  return !layered && d->pk_fs >= 0 && fused_eligible(d);
 }
 
 extern "C" int cinema_siren_pack(const cinema_siren_desc *d, const float *params, void *packed, void *stream) {
@@ -656,7 +666,7 @@ static int forward_impl(const cinema_siren_desc *d, const float *params, const v
     a.omega = i == 0 ? d->omega_first : d->omega_hidden;
     a.Y = sv + slot * d->sv_y[i];
     a.C = sv + slot * d->sv_c[i];
-    a.rowsW = HP; { const char *e = getenv("CINEMA_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.rowsW = HP;
     if (mod) {
       a.LAT = lat; a.LP = LP;
       a.Wls = pk + d->pk_wls[i];
@@ -707,6 +717,7 @@ extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *par
                  (long)N, (long)Npad);
   CINEMA_REQUIRE(Npad / 128 * ((d->HP + 127) / 128) < (1 << 30), "grid too large");
   hipStream_t s = (hipStream_t)stream;
+  if (use_fused(d)) return fused_forward(d, params, packed, coords_t, lat, N, Npad, saved, out, s);
   return d->precision == CINEMA_PREC_BF16
              ? forward_impl<bf16_t>(d, params, packed, coords_t, lat, N, Npad, saved, out, s)
              : forward_impl<float>(d, params, packed, coords_t, lat, N, Npad, saved, out, s);

@@ -80,6 +80,10 @@ typedef struct cinema_siren_desc {
   /* slot indices ([Npad x HP] tensors) */
   int32_t sv_y[CINEMA_MAX_LAYERS], sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
   int32_t gb_z[CINEMA_MAX_LAYERS], gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS];
+  /* bf16, hidden <= 512: per-wave MFMA-fragment weight streams of the activation-stationary kernels (offsets in
+   * elements into the packed copy, k32 steps per 64-feature slab); -1 / 0 when that path does not apply */
+  int64_t pk_fs, pk_bs;
+  int32_t fs_steps, bs_steps;
 } cinema_siren_desc;
 
 int cinema_siren_plan(cinema_siren_desc *d /* host */);
