@@ -15,7 +15,7 @@ BWD_SKIP_WEIGHT_GRADS = 1
 BWD_PHASE_CHAIN, BWD_PHASE_DLAT, BWD_PHASE_DW, BWD_PHASE_FINAL_DW = 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcinema_hip.so")
+LIB_PATH = os.environ.get("CINEMA_HIP_LIB") or os.path.join(_HERE, "libcinema_hip.so")   # override: developer builds
 
 
 class SirenDesc(C.Structure):

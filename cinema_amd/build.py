@@ -26,14 +26,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, trace: bool = False) -> str:
+    """trace=True builds the developer variant libcinema_hip_trace.so (phase timestamps inside the fused kernels;
+    load it with CINEMA_HIP_LIB=<path>)."""
+    out = OUT.replace(".so", "_trace.so") if trace else OUT
+    if not force and not trace and not needs_build():
         return OUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + SOURCES
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out] + SOURCES
+    if trace:
+        cmd.insert(1, "-DFUSED_TRACE_BUILD")
     if verbose:
         print("[cinema_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 namespace {
 
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+inline int ksteps(int k) { return round_up_i(k / 32, FUSED_RING); }   // k32 steps of a segment, padded to the ring
 
 // ----------------------------------------------------------------------------------------
 // stream plans (host)
@@ -34,9 +35,9 @@ void plan_fwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
   p.nseg = 0; p.steps = 0;
   for (int i = 0; i < d->n_layers; ++i) {
     const bool mod = (d->modulated_mask >> i) & 1u;
-    if (mod) plan_add(p, d->off_wl[i], L, H, L, 0, d->LP / 32);
-    if (i > 0) plan_add(p, d->off_w[i], H, H, H, 0, d->HP / 32);
-    if (mod) plan_add(p, d->off_wl[i] + (long)H * L, L, H, L, 0, d->LP / 32);
+    if (mod) plan_add(p, d->off_wl[i], L, H, L, 0, ksteps(d->LP));
+    if (i > 0) plan_add(p, d->off_w[i], H, H, H, 0, ksteps(d->HP));
+    if (mod) plan_add(p, d->off_wl[i] + (long)H * L, L, H, L, 0, ksteps(d->LP));
   }
 }
 
@@ -44,7 +45,7 @@ void plan_fwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
 void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
   const int H = d->hidden;
   p.nseg = 0; p.steps = 0;
-  for (int i = d->n_layers - 2; i >= 0; --i) plan_add(p, d->off_w[i + 1], H, H, H, 1, d->HP / 32);
+  for (int i = d->n_layers - 2; i >= 0; --i) plan_add(p, d->off_w[i + 1], H, H, H, 1, ksteps(d->HP));
 }
 
 struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg, steps, nslab; const float *params; bf16_t *dst; };
@@ -108,34 +109,18 @@ __device__ __forceinline__ void ring_init(WRing &r, const char *stream, unsigned
         acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
     ring_fetch(r.s[SLOT], r.wp, lane16);                                                                     \
     r.wp += 4096;                                                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* keep the refill here: hipcc otherwise sinks all refills of a group */ \
   }
 
-// acc[f][n] += sum_k A_stream[f][k] * tile[n][k] over nsteps (even) k32 steps of the wave's weight stream.
-// Ring slots are addressed statically (a run-time slot parity makes hipcc keep every slot twice and spill): slot 0
-// always holds the next step at segment boundaries; a segment of 4m+2 steps ends by renaming slots 2,3 -> 0,1.
+// acc[f][n] += sum_k A_stream[f][k] * tile[n][k] over nsteps k32 steps of the wave's weight stream.  Every segment
+// is padded to a multiple of FUSED_RING steps (zero weights against zeroed LDS columns), so the ring phase is always
+// 0 at a segment boundary and the slots are addressed statically (a run-time slot index makes hipcc keep every slot
+// twice and spill; with static slots its own counted vmcnt(15..12) waits come out exact).
 __device__ __forceinline__ void run_seg(f32x4 (&acc)[4][4], WRing &r, const lds_char *tile, int rowbytes, int nsteps,
                                         int i, int gk, unsigned lane16) {
   const int rowoff = i * rowbytes;
-  int k = 0;
-  for (; k + 4 <= nsteps; k += 4) {
+  for (int k = 0; k < nsteps; k += 4) {
     FUSED_STEP(0, k) FUSED_STEP(1, k + 1) FUSED_STEP(2, k + 2) FUSED_STEP(3, k + 3)
-  }
-  if (k < nsteps) {
-#define FUSED_TAIL(SLOT, KSTEP)                                                                              \
-  {                                                                                                          \
-    const int off_ = ((((KSTEP) << 2) + gk) ^ i) << 4;                                                       \
-    bf16x8 b_[4];                                                                                            \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                         \
-      b_[st] = *(const LDS_AS bf16x8 *)(tile + rowoff + st * 16 * rowbytes + off_);                          \
-    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                         \
-      _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                       \
-        acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
-    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft) r.s[SLOT][ft] = r.s[SLOT + 2][ft];                      \
-    ring_fetch(r.s[SLOT + 2], r.wp, lane16);                                                                 \
-    r.wp += 4096;                                                                                            \
-  }
-    FUSED_TAIL(0, k) FUSED_TAIL(1, k + 1)
-#undef FUSED_TAIL
   }
 }
 static_assert(FUSED_RING == 4, "run_seg is written for a 4-step ring");
@@ -147,14 +132,20 @@ __device__ __forceinline__ void fill_acc(f32x4 (&acc)[4][4], const f32x4 (&v)[4]
     for (int st = 0; st < 4; ++st) acc[ft][st] = v[ft];
 }
 
-// v[q] = p[fb + 4q .. +3] (fb, limit multiples of 16: the 16 features of a lane are all valid or all padding)
-__device__ __forceinline__ void feature_vec(const float *p, unsigned fb, int limit, f32x4 (&v)[4]) {
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const bool ok = (int)fb < limit;
-  const char *pc = (const char *)p;
+// v[q] = bias[off + fb + 4q .. +3] from the LDS copy of the biases (each vector zero-padded to HP)
+__device__ __forceinline__ void feature_vec(const lds_char *bias, int off, unsigned fb, f32x4 (&v)[4]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = ok ? *reinterpret_cast<const f32x4 *>(pc + (fb * 4u + q * 16u)) : zero;
+  for (int q = 0; q < 4; ++q) v[q] = *(const LDS_AS f32x4 *)(bias + ((off + fb) * 4u + q * 16u));
 }
+
+// optional phase trace of one wave (tools/trace_fused.py): 100 MHz timestamps
+__device__ long long g_fused_trace[128];
+#ifdef FUSED_TRACE_BUILD   // perturbs register allocation: only in the libcinema_hip_trace.so developer build
+#define FUSED_TRACE(ID) \
+  if (a.trace_block == (int)blockIdx.x && (int)threadIdx.x == a.trace_wave * 64) g_fused_trace[ID] = (long long)wall_clock64();
+#else
+#define FUSED_TRACE(ID)
+#endif
 
 __device__ __forceinline__ void pack16(const float (&v)[16], bf16x8 &lo, bf16x8 &hi) {
 #pragma unroll
@@ -174,13 +165,16 @@ struct FusedFwdArgs {
   bf16_t *saved; long slot;
   int sv_y[CINEMA_MAX_LAYERS], sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
   const bf16_t *wf; const float *bf; float *out;
-  int xrow, lrow;
+  int xrow, lrow, xsteps, lsteps;
+  int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;   // LDS bias copy: float offsets
+  int trace_block, trace_wave;
 };
 
 __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *xs = (lds_char *)smem;
   lds_char *ls = xs + FUSED_TS * a.xrow;
+  lds_char *bs = ls + FUSED_TS * a.lrow;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
   const int i = lane & 15, g = lane >> 4, gk = g;
@@ -193,6 +187,13 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   const unsigned toff = (i * a.HP + fb) * 2u;
   const unsigned tstep = 16u * a.HP * 2u;
 
+  FUSED_TRACE(0)
+  // zero both tiles: the k-padding columns are multiplied by zero weights and must not hold NaN bit patterns
+  {
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int q = tid; q < FUSED_TS * (a.xrow + a.lrow) / 16; q += 512) *(LDS_AS u32x4 *)(xs + q * 16) = z4;
+  }
+  __syncthreads();
   // latent rows of this tile -> LDS (swizzled 16-B chunks)
   {
     const int cpr = a.LP >> 3;  // chunks per row
@@ -203,9 +204,22 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       *(LDS_AS u32x4 *)(ls + row * a.lrow + ((c ^ (row & 15)) << 4)) = v;
     }
   }
+  // biases of every layer -> LDS
+  for (int l = 0; l < a.n_layers; ++l) {
+    const bool mod = (a.mod_mask >> l) & 1u;
+    for (int f = tid; f < a.HP; f += 512) {
+      const bool ok = f < a.H;
+      ((LDS_AS float *)bs)[a.lb_b[l] + f] = ok ? a.params[a.off_b[l] + f] : 0.f;
+      if (mod) {
+        ((LDS_AS float *)bs)[a.lb_bl[l] + f] = ok ? a.params[a.off_bl[l] + f] : 0.f;
+        ((LDS_AS float *)bs)[a.lb_bl[l] + a.HP + f] = ok ? a.params[a.off_bl[l] + a.H + f] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
   WRing r;
   if (active) ring_init(r, (const char *)(a.stream + (long)slab * a.slab_elems), lane16);
-  __syncthreads();
+  FUSED_TRACE(1)
 
   f32x4 acc[4][4];
 #pragma nounroll
@@ -223,9 +237,10 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       // the phase below uses exactly the value the backward will read
       bf16x8 sp[4][2];
       if (mod) {
-        feature_vec(a.params + a.off_bl[l], fb_l, a.H, v);
+        feature_vec(bs, a.lb_bl[l], fb_l, v);
         fill_acc(acc, v);
-        run_seg(acc, r, ls, a.lrow, a.LP >> 5, i_l, gk, lane16);
+        run_seg(acc, r, ls, a.lrow, a.lsteps, i_l, gk, lane16);
+        FUSED_TRACE(2 + 8 * l)
         char *S = (char *)(a.saved + a.slot * a.sv_s[l] + n0 * a.HP);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
           *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
         }
       }
-      feature_vec(a.params + a.off_b[l], fb_l, a.H, v);
+      feature_vec(bs, a.lb_b[l], fb_l, v);
       fill_acc(acc, v);
       if (l == 0) {
         // first layer: K = in_dim <= 3 on the VALU in fp32
@@ -255,11 +270,12 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
             for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w[j] * xv[st];
         }
       } else {
-        run_seg(acc, r, xs, a.xrow, a.HP >> 5, i_l, gk, lane16);
+        run_seg(acc, r, xs, a.xrow, a.xsteps, i_l, gk, lane16);
       }
+      FUSED_TRACE(3 + 8 * l)
       if (mod) {
         f32x4 bt[4];
-        feature_vec(a.params + a.off_bl[l] + a.H, fb_l, a.H, bt);
+        feature_vec(bs, a.lb_bl[l] + a.HP, fb_l, bt);
         char *Z = (char *)(a.saved + a.slot * a.sv_z[l] + n0 * a.HP);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -276,10 +292,12 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
             acc[j >> 2][st][j & 3] = omega * zv[j] * sj + bt[j >> 2][j & 3];
           }
         }
-        run_seg(acc, r, ls, a.lrow, a.LP >> 5, i_l, gk, lane16);
+        run_seg(acc, r, ls, a.lrow, a.lsteps, i_l, gk, lane16);
       }
+      FUSED_TRACE(4 + 8 * l)
     }
     __syncthreads();  // every wave has finished reading x
+    FUSED_TRACE(5 + 8 * l)
     if (active) {
       char *Y = (char *)(a.saved + a.slot * a.sv_y[l] + n0 * a.HP);
       char *C = (char *)(a.saved + a.slot * a.sv_c[l] + n0 * a.HP);
@@ -306,7 +324,9 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
         *(LDS_AS bf16x8 *)(xr + (((c0 + 1) ^ i_l) << 4)) = yhi;
       }
     }
+    FUSED_TRACE(6 + 8 * l)
     __syncthreads();  // x of the next layer is complete
+    FUSED_TRACE(7 + 8 * l)
   }
 
   // final linear (siren.py:61): out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]; wave w < 4 takes sample tile w
@@ -336,6 +356,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       if (o < a.out_dim) ot[(unsigned)(i * a.out_dim + o)] = o4[rr] + a.bf[o];
     }
   }
+  FUSED_TRACE(127)
 }
 
 }  // namespace
@@ -343,8 +364,14 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
 // ========================================================================================
 // host side
 // ========================================================================================
+static int fused_bias_floats(const cinema_siren_desc *d) {
+  int n = 0;
+  for (int i = 0; i < d->n_layers; ++i) n += d->HP * (((d->modulated_mask >> i) & 1u) ? 3 : 1);
+  return n;
+}
+
 static int fused_lds_bytes(const cinema_siren_desc *d) {
-  return FUSED_TS * (round_up_i(d->HP * 2, 256) + round_up_i(d->LP * 2, 256));
+  return FUSED_TS * 64 * (ksteps(d->HP) + ksteps(d->LP)) + 4 * fused_bias_floats(d);
 }
 
 bool fused_eligible(const cinema_siren_desc *d) {
@@ -385,6 +412,15 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
   return 0;
 }
 
+// developer hook (not part of the C ABI in include/): choose the workgroup / wave whose phase timestamps the next
+// forward launches record, and read them back
+static int g_trace_block = -1, g_trace_wave = 0;
+extern "C" int cinema_debug_fused_trace(int block, int wave, long long *host_out128) {
+  g_trace_block = block; g_trace_wave = wave;
+  if (host_out128) CINEMA_CHECK_HIP(hipMemcpyFromSymbol(host_out128, HIP_SYMBOL(g_fused_trace), sizeof(long long) * 128));
+  return 0;
+}
+
 int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                   const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "fused_forward: descriptor not planned for the fused path");
@@ -396,7 +432,11 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   for (int i = 0; i < d->n_layers; ++i) {
     a.off_b[i] = d->off_b[i]; a.off_bl[i] = d->off_bl[i];
     a.sv_y[i] = d->sv_y[i]; a.sv_c[i] = d->sv_c[i]; a.sv_z[i] = d->sv_z[i]; a.sv_s[i] = d->sv_s[i];
+    a.lb_b[i] = a.lb_total; a.lb_total += d->HP;
+    a.lb_bl[i] = a.lb_total;
+    if ((d->modulated_mask >> i) & 1u) a.lb_total += 2 * d->HP;
   }
+  a.trace_block = g_trace_block; a.trace_wave = g_trace_wave;
   a.off_w0 = d->off_w[0];
   a.mod_mask = d->modulated_mask; a.n_layers = d->n_layers; a.in_dim = d->in_dim;
   a.H = d->hidden; a.HP = d->HP; a.LP = d->LP; a.out_dim = d->out_dim;
@@ -404,7 +444,8 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   a.coords_t = coords_t; a.lat = (const bf16_t *)lat;
   a.saved = (bf16_t *)saved; a.slot = (long)Npad * d->HP;
   a.wf = (const bf16_t *)packed + d->pk_wf; a.bf = params + d->off_bf; a.out = out;
-  a.xrow = round_up_i(d->HP * 2, 256); a.lrow = round_up_i(d->LP * 2, 256);
+  a.xsteps = ksteps(d->HP); a.lsteps = ksteps(d->LP);
+  a.xrow = 64 * a.xsteps; a.lrow = 64 * a.lsteps;
   const int smem = fused_lds_bytes(d);
   static int attr_smem = 0;
   if (smem > attr_smem) {
