@@ -75,6 +75,33 @@ __global__ void k_pack_stream(PackStreamArgs a) {
   }
 }
 
+// fp32 side block in exactly the layout the forward kernel keeps in LDS (zero padded to HP per vector):
+//   per layer [b_l] [bl_scale, bl_shift if modulated] ... then w0 as [HP][4] (k = 0..2, pad)
+struct PackSideArgs {
+  const float *params; float *dst;
+  long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0;
+  int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;
+  unsigned mod_mask; int n_layers, H, HP, in_dim;
+};
+
+__global__ void k_pack_side(PackSideArgs a) {
+  const int total = a.lb_total + 4 * a.HP;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    float x = 0.f;
+    if (e >= a.lb_total) {
+      const int q = e - a.lb_total, f = q >> 2, k = q & 3;
+      if (f < a.H && k < a.in_dim) x = a.params[a.off_w0 + (long)f * a.in_dim + k];
+    } else {
+      int l = 0;
+      while (l + 1 < a.n_layers && e >= a.lb_b[l + 1]) ++l;
+      const int q = e - a.lb_b[l];
+      const int part = q / a.HP, f = q - part * a.HP;      // 0: b, 1: bl scale, 2: bl shift
+      if (f < a.H) x = part == 0 ? a.params[a.off_b[l] + f] : a.params[a.off_bl[l] + (long)(part - 1) * a.H + f];
+    }
+    a.dst[e] = x;
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // device: weight ring + segment runner
 // ----------------------------------------------------------------------------------------
@@ -166,7 +193,8 @@ struct FusedFwdArgs {
   int sv_y[CINEMA_MAX_LAYERS], sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
   const bf16_t *wf; const float *bf; float *out;
   int xrow, lrow, xsteps, lsteps;
-  int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;   // LDS bias copy: float offsets
+  int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;   // LDS side block: float offsets
+  const float *side;
   int trace_block, trace_wave;
 };
 
@@ -188,37 +216,32 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   const unsigned tstep = 16u * a.HP * 2u;
 
   FUSED_TRACE(0)
-  // zero both tiles: the k-padding columns are multiplied by zero weights and must not hold NaN bit patterns
-  {
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    for (int q = tid; q < FUSED_TS * (a.xrow + a.lrow) / 16; q += 512) *(LDS_AS u32x4 *)(xs + q * 16) = z4;
-  }
-  __syncthreads();
-  // latent rows of this tile -> LDS (swizzled 16-B chunks)
-  {
-    const int cpr = a.LP >> 3;  // chunks per row
-    const char *lt = (const char *)(a.lat + n0 * a.LP);
-    for (int q = tid; q < FUSED_TS * cpr; q += 512) {
-      const int row = q / cpr, c = q - row * cpr;
-      const u32x4 v = *reinterpret_cast<const u32x4 *>(lt + (unsigned)(row * a.LP + c * 8) * 2u);
-      *(LDS_AS u32x4 *)(ls + row * a.lrow + ((c ^ (row & 15)) << 4)) = v;
-    }
-  }
-  // biases of every layer -> LDS
-  for (int l = 0; l < a.n_layers; ++l) {
-    const bool mod = (a.mod_mask >> l) & 1u;
-    for (int f = tid; f < a.HP; f += 512) {
-      const bool ok = f < a.H;
-      ((LDS_AS float *)bs)[a.lb_b[l] + f] = ok ? a.params[a.off_b[l] + f] : 0.f;
-      if (mod) {
-        ((LDS_AS float *)bs)[a.lb_bl[l] + f] = ok ? a.params[a.off_bl[l] + f] : 0.f;
-        ((LDS_AS float *)bs)[a.lb_bl[l] + a.HP + f] = ok ? a.params[a.off_bl[l] + a.H + f] : 0.f;
-      }
-    }
-  }
-  __syncthreads();
   WRing r;
   if (active) ring_init(r, (const char *)(a.stream + (long)slab * a.slab_elems), lane16);
+  lds_char *cs = bs + (a.lb_total + 4 * a.HP) * 4;      // registered coordinates of the tile, [64][4] fp32
+  {
+    // latent rows -> LDS (swizzled 16-B chunks); the k-padding chunks meet zero weights and must not hold NaN patterns
+    const int cpr = a.lrow >> 4, cdat = a.LP >> 3;
+    const char *lt = (const char *)(a.lat + n0 * a.LP);
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int q = tid; q < FUSED_TS * cpr; q += 512) {
+      const int row = q / cpr, c = q - row * cpr;
+      u32x4 v = z4;
+      if (c < cdat) v = *reinterpret_cast<const u32x4 *>(lt + (unsigned)(row * a.LP + c * 8) * 2u);
+      *(LDS_AS u32x4 *)(ls + row * a.lrow + ((c ^ (row & 15)) << 4)) = v;
+    }
+    if (a.xrow != a.HP * 2)
+      for (int q = tid; q < FUSED_TS * a.xrow / 16; q += 512) *(LDS_AS u32x4 *)(xs + q * 16) = z4;
+    // biases + first-layer weights: one coalesced copy of the block k_pack_side prepared
+    const int nb4 = (a.lb_total + 4 * a.HP) / 4;
+    for (int q = tid; q < nb4; q += 512) *(LDS_AS f32x4 *)(bs + q * 16) = *reinterpret_cast<const f32x4 *>(a.side + q * 4);
+    if (tid < FUSED_TS) {
+      const float *cp = a.coords_t + (n0 + tid) * a.in_dim;
+      f32x4 c = {cp[0], a.in_dim > 1 ? cp[1] : 0.f, a.in_dim > 2 ? cp[2] : 0.f, 0.f};
+      *(LDS_AS f32x4 *)(cs + tid * 16) = c;
+    }
+  }
+  __syncthreads();
   FUSED_TRACE(1)
 
   f32x4 acc[4][4];
@@ -255,19 +278,15 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       feature_vec(bs, a.lb_b[l], fb_l, v);
       fill_acc(acc, v);
       if (l == 0) {
-        // first layer: K = in_dim <= 3 on the VALU in fp32
-        const float *ct = a.coords_t + n0 * a.in_dim;
-        const float *w0 = a.params + a.off_w0;
-        for (int k = 0; k < a.in_dim; ++k) {
-          float xv[4], w[16];
+        // first layer: K = in_dim <= 3 on the VALU in fp32, operands from LDS
+        f32x4 c[4];
 #pragma unroll
-          for (int st = 0; st < 4; ++st) xv[st] = ct[(unsigned)((16 * st + i_l) * a.in_dim + k)];
+        for (int st = 0; st < 4; ++st) c[st] = *(const LDS_AS f32x4 *)(cs + (16 * st + i_l) * 16);
 #pragma unroll
-          for (int j = 0; j < 16; ++j) w[j] = ((int)fb_l < a.H) ? w0[(fb_l + j) * (unsigned)a.in_dim + k] : 0.f;
+        for (int j = 0; j < 16; ++j) {
+          const f32x4 w = *(const LDS_AS f32x4 *)(bs + (a.lb_total + (fb_l + j) * 4) * 4);
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w[j] * xv[st];
+          for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w[0] * c[st][0] + w[1] * c[st][1] + w[2] * c[st][2];
         }
       } else {
         run_seg(acc, r, xs, a.xrow, a.xsteps, i_l, gk, lane16);
@@ -337,17 +356,24 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
     const unsigned woff = (i * KT + 8 * gk) * 2u;
     const lds_char *xrp = xs + (16 * st + i) * a.xrow;
     const lds_char *lrp = ls + (16 * st + i) * a.lrow;
-#pragma unroll 4
-    for (int k = 0; k < (a.HP >> 5); ++k) {
-      const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wrow + (woff + 64u * k));
-      const bf16x8 b = *(const LDS_AS bf16x8 *)(xrp + ((((k << 2) + gk) ^ i) << 4));
-      o4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, o4, 0, 0, 0);
-    }
-#pragma unroll 2
-    for (int k = 0; k < (a.LP >> 5); ++k) {
-      const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wrow + (woff + 2u * a.HP + 64u * k));
-      const bf16x8 b = *(const LDS_AS bf16x8 *)(lrp + ((((k << 2) + gk) ^ i) << 4));
-      o4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, o4, 0, 0, 0);
+    // all A fragments of a group are fetched before its first MFMA (26 dependent L2 round trips otherwise)
+    const int nx = a.HP >> 5, nsteps = nx + (a.LP >> 5);
+    for (int k0 = 0; k0 < nsteps; k0 += 8) {
+      bf16x8 w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = k0 + k < nsteps ? k0 + k : nsteps - 1;
+        w[k] = *reinterpret_cast<const bf16x8 *>(wrow + (woff + 64u * kk));     // Wf row is [x part | lat part], k contiguous
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = k0 + k;
+        if (kk < nsteps) {
+          const lds_char *src = kk < nx ? xrp + (((((kk) << 2) + gk) ^ i) << 4) : lrp + (((((kk - nx) << 2) + gk) ^ i) << 4);
+          const bf16x8 b = *(const LDS_AS bf16x8 *)src;
+          o4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k], b, o4, 0, 0, 0);
+        }
+      }
     }
     float *ot = a.out + (n0 + 16 * st) * a.out_dim;
 #pragma unroll
@@ -371,7 +397,7 @@ static int fused_bias_floats(const cinema_siren_desc *d) {
 }
 
 static int fused_lds_bytes(const cinema_siren_desc *d) {
-  return FUSED_TS * 64 * (ksteps(d->HP) + ksteps(d->LP)) + 4 * fused_bias_floats(d);
+  return FUSED_TS * 64 * (ksteps(d->HP) + ksteps(d->LP)) + 4 * (fused_bias_floats(d) + 4 * d->HP) + FUSED_TS * 16;
 }
 
 bool fused_eligible(const cinema_siren_desc *d) {
@@ -379,7 +405,7 @@ bool fused_eligible(const cinema_siren_desc *d) {
 }
 
 void fused_plan(cinema_siren_desc *d, long *pk) {
-  d->pk_fs = d->pk_bs = -1;
+  d->pk_fs = d->pk_bs = d->pk_side = -1;
   d->fs_steps = d->bs_steps = 0;
   if (!fused_eligible(d)) return;
   StreamPlan p;
@@ -391,11 +417,13 @@ void fused_plan(cinema_siren_desc *d, long *pk) {
   d->pk_bs = *pk; d->bs_steps = p.steps;
   *pk += nslab * p.steps * FUSED_STEP_ELEMS;
   *pk += (long)FUSED_RING * FUSED_STEP_ELEMS;  // zero pad: the rings prefetch past the end of the last slab
+  d->pk_side = *pk;                            // fp32 side block (biases, first-layer weights) in a T-typed buffer
+  *pk += 2L * (fused_bias_floats(d) + 4 * d->HP);
 }
 
 int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
   if (d->pk_fs < 0) return 0;
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 1; ++which) {   // the backward stream (which == 1) has no consumer yet
     StreamPlan p;
     if (which == 0) plan_fwd_stream(d, p); else plan_bwd_stream(d, p);
     if (p.steps == 0) continue;
@@ -409,6 +437,18 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
     hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
+  PackSideArgs b = {};
+  b.params = params; b.dst = (float *)((bf16_t *)packed + d->pk_side);
+  for (int i = 0; i < d->n_layers; ++i) {
+    b.off_b[i] = d->off_b[i]; b.off_bl[i] = d->off_bl[i];
+    b.lb_b[i] = b.lb_total; b.lb_total += d->HP;
+    b.lb_bl[i] = b.lb_total;
+    if ((d->modulated_mask >> i) & 1u) b.lb_total += 2 * d->HP;
+  }
+  b.off_w0 = d->off_w[0];
+  b.mod_mask = d->modulated_mask; b.n_layers = d->n_layers; b.H = d->hidden; b.HP = d->HP; b.in_dim = d->in_dim;
+  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 4 * d->HP + 255) / 256), dim3(256), 0, s, b);
+  CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
@@ -437,6 +477,7 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
     if ((d->modulated_mask >> i) & 1u) a.lb_total += 2 * d->HP;
   }
   a.trace_block = g_trace_block; a.trace_wave = g_trace_wave;
+  a.side = (const float *)((const bf16_t *)packed + d->pk_side);
   a.off_w0 = d->off_w[0];
   a.mod_mask = d->modulated_mask; a.n_layers = d->n_layers; a.in_dim = d->in_dim;
   a.H = d->hidden; a.HP = d->HP; a.LP = d->LP; a.out_dim = d->out_dim;

@@ -343,12 +343,16 @@ template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using E = Engine<T>;
-  const int bid = blockIdx.x;
-  const int tile = bid / a.splitk, split = bid - tile * a.splitk;
+  // XCD-aware order: blocks that share an XCD get a contiguous range of logical ids, and logical ids walk
+  // problem -> sample split -> tile, so the tiles that read the same operand slabs (same problem, same sample range)
+  // run together behind one L2 instead of being dealt round-robin over the eight XCDs.
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
-  while (pi + 1 < a.nprob && tile >= a.tile_start[pi + 1]) ++pi;
+  while (pi + 1 < a.nprob && lid >= a.tile_start[pi + 1] * a.splitk) ++pi;
   const DwProb pr = a.p[pi];
-  const int t = tile - a.tile_start[pi];
+  const int ntp = a.tile_start[pi + 1] - a.tile_start[pi];
+  const int rel = lid - a.tile_start[pi] * a.splitk;
+  const int split = rel / ntp, t = rel - split * ntp;
   const int h0 = (t / pr.tk) * 128, c0 = (t % pr.tk) * 128;
   const int ntile = a.Npad / E::BN;
   const int nbeg = (int)((long)ntile * split / a.splitk) * E::BN;
@@ -570,6 +574,13 @@ extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
   return 0;
 }
 
+// The activation-stationary kernels serve bf16 stacks up to hidden 512; CINEMA_SIREN_LAYERED=1 forces the
+// layer-by-layer kernels (the only path for fp32 and wider stacks) so tests can cover both.
+static int fused_mode(const cinema_siren_desc *d) {   // 0 = layered kernels, 64 = samples per workgroup of fused.hip
+  static const bool layered = [] { const char *e = getenv("CINEMA_SIREN_LAYERED"); return e && e[0] == '1'; }();
+  return (!layered && d->pk_fs >= 0 && fused_eligible(d)) ? 64 : 0;
+}
+
 template <typename T>
 static int pack_impl(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
   PackArgs a;
@@ -589,15 +600,20 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
     a.job[nj++] = j;
     return nj == PACK_MAX_JOBS ? flush() : 0;
   };
+  // the row-major forward copies are only read by the layer-by-layer forward kernels
+  const bool fwd_layered = fused_mode(d) == 0;
   for (int i = 0; i < d->n_layers; ++i) {
     if (i > 0) {
-      if (int rc = add(params + d->off_w[i], d->pk_w[i], H, H, H, HP, HP, 0)) return rc;
+      if (fwd_layered)
+        if (int rc = add(params + d->off_w[i], d->pk_w[i], H, H, H, HP, HP, 0)) return rc;
       if (int rc = add(params + d->off_w[i], d->pk_wt[i], H, H, H, HP, HP, 1)) return rc;
     }
     if ((d->modulated_mask >> i) & 1u) {
       const float *wl = params + d->off_wl[i];
-      if (int rc = add(wl, d->pk_wls[i], H, L, L, HP, LP, 0)) return rc;
-      if (int rc = add(wl + (size_t)H * L, d->pk_wlt[i], H, L, L, HP, LP, 0)) return rc;
+      if (fwd_layered) {
+        if (int rc = add(wl, d->pk_wls[i], H, L, L, HP, LP, 0)) return rc;
+        if (int rc = add(wl + (size_t)H * L, d->pk_wlt[i], H, L, L, HP, LP, 0)) return rc;
+      }
       if (int rc = add(wl, d->pk_wlsT[i], H, L, L, LP, HP, 1)) return rc;
       if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
     }
@@ -620,14 +636,7 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
   dim3 grid2(1, nb);
   hipLaunchKernelGGL((k_pack<T>), grid2, dim3(256), 0, s, b);
   CINEMA_CHECK_HIP(hipGetLastError());
-  return fused_pack(d, params, packed, s);
-}
-
-// The activation-stationary kernels serve bf16 stacks up to hidden 512; CINEMA_SIREN_LAYERED=1 forces the
-// layer-by-layer kernels (the only path for fp32 and wider stacks) so tests can cover both.
-static bool use_fused(const cinema_siren_desc *d) {
-  static const bool layered = [] { const char *e = getenv("CINEMA_SIREN_LAYERED"); return e && e[0] == '1'; }();
-  return !layered && d->pk_fs >= 0 && fused_eligible(d);
+  return fwd_layered ? 0 : fused_pack(d, params, packed, s);
 }
 
 extern "C" int cinema_siren_pack(const cinema_siren_desc *d, const float *params, void *packed, void *stream) {
@@ -717,7 +726,7 @@ extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *par
                  (long)N, (long)Npad);
   CINEMA_REQUIRE(Npad / 128 * ((d->HP + 127) / 128) < (1 << 30), "grid too large");
   hipStream_t s = (hipStream_t)stream;
-  if (use_fused(d)) return fused_forward(d, params, packed, coords_t, lat, N, Npad, saved, out, s);
+  if (fused_mode(d) == 64) return fused_forward(d, params, packed, coords_t, lat, N, Npad, saved, out, s);
   return d->precision == CINEMA_PREC_BF16
              ? forward_impl<bf16_t>(d, params, packed, coords_t, lat, N, Npad, saved, out, s)
              : forward_impl<float>(d, params, packed, coords_t, lat, N, Npad, saved, out, s);

@@ -82,7 +82,7 @@ typedef struct cinema_siren_desc {
   int32_t gb_z[CINEMA_MAX_LAYERS], gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS];
   /* bf16, hidden <= 512: per-wave MFMA-fragment weight streams of the activation-stationary kernels (offsets in
    * elements into the packed copy, k32 steps per 64-feature slab); -1 / 0 when that path does not apply */
-  int64_t pk_fs, pk_bs;
+  int64_t pk_fs, pk_bs, pk_side;   /* pk_side: fp32 block of biases + first-layer weights in the kernel's LDS layout */
   int32_t fs_steps, bs_steps;
 } cinema_siren_desc;
 
