@@ -18,3 +18,6 @@ void fused_plan(cinema_siren_desc *d, long *pk);                   // appends th
 int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s);
 int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                   const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s);
+int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
+                         const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
+                         hipStream_t s);

@@ -76,19 +76,24 @@ __global__ void k_pack_stream(PackStreamArgs a) {
 }
 
 // fp32 side block in exactly the layout the forward kernel keeps in LDS (zero padded to HP per vector):
-//   per layer [b_l] [bl_scale, bl_shift if modulated] ... then w0 as [HP][4] (k = 0..2, pad)
+//   per layer [b_l] [bl_scale, bl_shift if modulated] ... then w0 as [HP][4] (k = 0..2, pad), then (backward only)
+//   final_linear.weight[:, :H] as [16][HP]
 struct PackSideArgs {
   const float *params; float *dst;
   long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0;
   int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;
   unsigned mod_mask; int n_layers, H, HP, in_dim;
+  long off_wf; int out_dim, lat;
 };
 
 __global__ void k_pack_side(PackSideArgs a) {
-  const int total = a.lb_total + 4 * a.HP;
+  const int total = a.lb_total + 4 * a.HP + 16 * a.HP;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     float x = 0.f;
-    if (e >= a.lb_total) {
+    if (e >= a.lb_total + 4 * a.HP) {          // final_linear.weight[:, :H] as [16][HP] (backward, top of the chain)
+      const int q = e - a.lb_total - 4 * a.HP, o = q / a.HP, f = q - o * a.HP;
+      if (o < a.out_dim && f < a.H) x = a.params[a.off_wf + (long)o * (a.H + a.lat) + f];
+    } else if (e >= a.lb_total) {
       const int q = e - a.lb_total, f = q >> 2, k = q & 3;
       if (f < a.H && k < a.in_dim) x = a.params[a.off_w0 + (long)f * a.in_dim + k];
     } else {
@@ -385,6 +390,219 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   FUSED_TRACE(127)
 }
 
+
+// ----------------------------------------------------------------------------------------
+// fused backward chain: the mirror of k_fused_fwd.  The gradient tile g = dz_{l+1} [64 x HP] stays in LDS from the
+// top of the stack to the first layer; per layer dy = W_{l+1}^T g streams the transposed weights, the epilogue applies
+// the sine / FiLM derivatives with the saved c (z, s), streams dz (ds, dt) out for the weight-gradient and d-latent
+// GEMMs, reduces the bias gradients and leaves dz in LDS as the next g.
+// ----------------------------------------------------------------------------------------
+struct FusedBwdArgs {
+  const bf16_t *stream; long slab_elems;
+  const float *side_w0;              // [HP][4] first-layer weights, then [16][HP] final_linear.weight[:, :H]
+  const float *dout; const float *coords_t;
+  const bf16_t *saved; long slot; int sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
+  bf16_t *gbuf; int gb_z[CINEMA_MAX_LAYERS], gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS];
+  float *gp; long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0; int wgrads;
+  float *dcoords;
+  unsigned mod_mask; int n_layers, in_dim, H, HP, out_dim, xrow, xsteps;
+  float om_first, om_hidden;
+};
+
+template <bool MOD, bool FIRST>
+__device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)[4][4], int l, float omega, long n0,
+                                             unsigned toff_l, unsigned tstep, unsigned fb_l, int i_l, int g, int lane,
+                                             lds_char *gs, const lds_char *w0s, const lds_char *cs) {
+      const char *C = (const char *)(a.saved + a.slot * a.sv_c[l] + n0 * a.HP);
+      const char *Z = MOD ? (const char *)(a.saved + a.slot * a.sv_z[l] + n0 * a.HP) : C;
+      const char *S = MOD ? (const char *)(a.saved + a.slot * a.sv_s[l] + n0 * a.HP) : C;
+      char *DZ = (char *)(a.gbuf + a.slot * a.gb_z[l] + n0 * a.HP);
+      char *DS = MOD ? (char *)(a.gbuf + a.slot * a.gb_s[l] + n0 * a.HP) : DZ;
+      char *DT = MOD ? (char *)(a.gbuf + a.slot * a.gb_t[l] + n0 * a.HP) : DZ;
+      const int c0 = fb_l >> 3;
+      // column sums (bias / first-layer weight gradients): each sample tile is transposed-reduced over its 16 lanes
+      // right away, so only one scalar per tensor stays live across the tiles instead of 16
+      float tz = 0.f, ts = 0.f, tt = 0.f, tw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const unsigned o = toff_l + st * tstep;
+        float cv[16], dz[16];
+        {
+          const bf16x8 lo = *reinterpret_cast<const bf16x8 *>(C + o), hi = *reinterpret_cast<const bf16x8 *>(C + o + 16u);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { cv[j] = (float)lo[j]; cv[8 + j] = (float)hi[j]; }
+        }
+        if constexpr (MOD) {
+          const bf16x8 zlo = *reinterpret_cast<const bf16x8 *>(Z + o), zhi = *reinterpret_cast<const bf16x8 *>(Z + o + 16u);
+          const bf16x8 slo = *reinterpret_cast<const bf16x8 *>(S + o), shi = *reinterpret_cast<const bf16x8 *>(S + o + 16u);
+          float ds[16], dt[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float zj = (float)(j < 8 ? zlo[j & 7] : zhi[j & 7]), sj = (float)(j < 8 ? slo[j & 7] : shi[j & 7]);
+            const float gq = acc[j >> 2][st][j & 3] * cv[j];
+            dt[j] = gq;
+            dz[j] = omega * gq * sj;
+            ds[j] = omega * gq * zj;
+          }
+          if (a.wgrads) {
+            ts += reduce16_scatter(ds, lane);
+            tt += reduce16_scatter(dt, lane);
+          }
+          bf16x8 lo, hi;
+          pack16(ds, lo, hi);
+          *reinterpret_cast<bf16x8 *>(DS + o) = lo;
+          *reinterpret_cast<bf16x8 *>(DS + o + 16u) = hi;
+          pack16(dt, lo, hi);
+          *reinterpret_cast<bf16x8 *>(DT + o) = lo;
+          *reinterpret_cast<bf16x8 *>(DT + o + 16u) = hi;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) dz[j] = omega * acc[j >> 2][st][j & 3] * cv[j];
+        }
+        bf16x8 zl, zh;
+        pack16(dz, zl, zh);
+        *reinterpret_cast<bf16x8 *>(DZ + o) = zl;
+        *reinterpret_cast<bf16x8 *>(DZ + o + 16u) = zh;
+        if constexpr (!FIRST) {
+          lds_char *xr = gs + (16 * st + i_l) * a.xrow;
+          *(LDS_AS bf16x8 *)(xr + ((c0 ^ i_l) << 4)) = zl;
+          *(LDS_AS bf16x8 *)(xr + (((c0 + 1) ^ i_l) << 4)) = zh;
+        } else {
+          // first layer: d coords = dz W0, dW0 = dz^T coords
+          const f32x4 xc = *(const LDS_AS f32x4 *)(cs + (16 * st + i_l) * 16);
+          float dc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const f32x4 w = *(const LDS_AS f32x4 *)(w0s + (fb_l + j) * 16);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dc[k] += dz[j] * w[k];
+          }
+          if (a.wgrads) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              float p[16];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) p[j] = dz[j] * xc[k];
+              tw[k] += reduce16_scatter(p, lane);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            dc[k] += __shfl_xor(dc[k], 16, 64);
+            dc[k] += __shfl_xor(dc[k], 32, 64);
+          }
+          if (g == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (k < a.in_dim) atomicAdd(a.dcoords + (n0 + 16 * st + i_l) * a.in_dim + k, dc[k]);
+          }
+        }
+        if (a.wgrads) tz += reduce16_scatter(dz, lane);
+        __builtin_amdgcn_sched_barrier(0);   // one sample tile at a time: bounds the live temporaries
+      }
+      // column sums over the 64 samples of this wave -> bias (and first-layer weight) gradients
+      if (a.wgrads) {
+        const int fi = fb_l + reduce16_index(i_l);
+        if (fi < a.H) atomicAdd(a.gp + a.off_b[l] + fi, tz);
+        if constexpr (MOD) {
+          if (fi < a.H) {
+            atomicAdd(a.gp + a.off_bl[l] + fi, ts);
+            atomicAdd(a.gp + a.off_bl[l] + a.H + fi, tt);
+          }
+        }
+        if constexpr (FIRST) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (k < a.in_dim && fi < a.H) atomicAdd(a.gp + a.off_w0 + (long)fi * a.in_dim + k, tw[k]);
+          }
+        }
+      }
+}
+
+__global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char *gs = (lds_char *)smem;                       // g tile [64][xrow] bf16, swizzled
+  lds_char *w0s = gs + FUSED_TS * a.xrow;                // [HP][4] fp32
+  lds_char *wfs = w0s + a.HP * 16;                       // [16][HP] fp32
+  lds_char *ds_ = wfs + 16 * a.HP * 4;                   // dOut tile [64][16] fp32
+  lds_char *cs = ds_ + FUSED_TS * 64;                    // coords tile [64][4] fp32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4, gk = g;
+  const long n0 = (long)blockIdx.x * FUSED_TS;
+  const int slab = wave;
+  const bool active = slab * 64 < a.HP;
+  const unsigned fb = slab * 64 + 16 * g;
+  const unsigned lane16 = lane * 16;
+  const unsigned toff = (i * a.HP + fb) * 2u;
+  const unsigned tstep = 16u * a.HP * 2u;
+
+  WRing r;
+  if (active && a.n_layers > 1) ring_init(r, (const char *)(a.stream + (long)slab * a.slab_elems), lane16);
+  {
+    const int nb4 = 20 * a.HP / 4;
+    for (int q = tid; q < nb4; q += 512) *(LDS_AS f32x4 *)(w0s + q * 16) = *reinterpret_cast<const f32x4 *>(a.side_w0 + q * 4);
+    for (int q = tid; q < FUSED_TS * 16; q += 512) {
+      const int row = q >> 4, o = q & 15;
+      ((LDS_AS float *)ds_)[q] = o < a.out_dim ? a.dout[(n0 + row) * a.out_dim + o] : 0.f;
+    }
+    if (tid < FUSED_TS) {
+      const float *cp = a.coords_t + (n0 + tid) * a.in_dim;
+      f32x4 c = {cp[0], a.in_dim > 1 ? cp[1] : 0.f, a.in_dim > 2 ? cp[2] : 0.f, 0.f};
+      *(LDS_AS f32x4 *)(cs + tid * 16) = c;
+    }
+    if (a.xrow != a.HP * 2) {
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      for (int q = tid; q < FUSED_TS * a.xrow / 16; q += 512) *(LDS_AS u32x4 *)(gs + q * 16) = z4;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma nounroll
+  for (int l = a.n_layers - 1; l >= 0; --l) {
+    const bool mod = (a.mod_mask >> l) & 1u;
+    const float omega = l == 0 ? a.om_first : a.om_hidden;
+    unsigned toff_l = toff, fb_l = fb;
+    int i_l = i;
+    asm volatile("" : "+v"(toff_l), "+v"(fb_l), "+v"(i_l));   // see k_fused_fwd
+    if (active) {
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) acc[ft][st] = zero4;
+      if (l == a.n_layers - 1) {
+        // top of the chain: dy[n][f] = sum_o dOut[n][o] * Wf[o][f] on the VALU
+        for (int o = 0; o < a.out_dim; ++o) {
+          float d[4];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) d[st] = ((const LDS_AS float *)ds_)[(16 * st + i_l) * 16 + o];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w = *(const LDS_AS f32x4 *)(wfs + ((o * a.HP + fb_l) * 4u + q * 16u));
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc[q][st] += w * d[st];
+          }
+        }
+      } else {
+        run_seg(acc, r, gs, a.xrow, a.xsteps, i_l, gk, lane16);
+      }
+    }
+    __syncthreads();  // every wave has finished reading g
+    if (active) {
+      if (l == 0) {
+        if (mod) bwd_epilogue<true, true>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, true>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+      } else {
+        if (mod) bwd_epilogue<true, false>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, false>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+      }
+    }
+    __syncthreads();  // g of the next (lower) layer is complete
+  }
+}
+
 }  // namespace
 
 // ========================================================================================
@@ -418,12 +636,12 @@ void fused_plan(cinema_siren_desc *d, long *pk) {
   *pk += nslab * p.steps * FUSED_STEP_ELEMS;
   *pk += (long)FUSED_RING * FUSED_STEP_ELEMS;  // zero pad: the rings prefetch past the end of the last slab
   d->pk_side = *pk;                            // fp32 side block (biases, first-layer weights) in a T-typed buffer
-  *pk += 2L * (fused_bias_floats(d) + 4 * d->HP);
+  *pk += 2L * (fused_bias_floats(d) + 4 * d->HP + 16 * d->HP);
 }
 
 int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
   if (d->pk_fs < 0) return 0;
-  for (int which = 0; which < 1; ++which) {   // the backward stream (which == 1) has no consumer yet
+  for (int which = 0; which < 2; ++which) {
     StreamPlan p;
     if (which == 0) plan_fwd_stream(d, p); else plan_bwd_stream(d, p);
     if (p.steps == 0) continue;
@@ -447,7 +665,8 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
   }
   b.off_w0 = d->off_w[0];
   b.mod_mask = d->modulated_mask; b.n_layers = d->n_layers; b.H = d->hidden; b.HP = d->HP; b.in_dim = d->in_dim;
-  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 4 * d->HP + 255) / 256), dim3(256), 0, s, b);
+  b.off_wf = d->off_wf; b.out_dim = d->out_dim; b.lat = d->lat;
+  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 20 * d->HP + 255) / 256), dim3(256), 0, s, b);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -496,5 +715,38 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(Npad / FUSED_TS)), dim3(512), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   (void)N;
+  return 0;
+}
+
+int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
+                         const float *dout, int64_t Npad, void *gbuf, float *gp, float *dcoords, bool wgrads,
+                         hipStream_t s) {
+  CINEMA_REQUIRE(fused_eligible(d) && d->pk_bs >= 0, "fused_backward_chain: descriptor not planned for the fused path");
+  CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_backward_chain: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
+  FusedBwdArgs a = {};
+  a.stream = (const bf16_t *)packed + d->pk_bs;
+  a.slab_elems = (long)d->bs_steps * FUSED_STEP_ELEMS;
+  a.side_w0 = (const float *)((const bf16_t *)packed + d->pk_side) + fused_bias_floats(d);
+  a.dout = dout; a.coords_t = coords_t;
+  a.saved = (const bf16_t *)saved; a.slot = (long)Npad * d->HP; a.gbuf = (bf16_t *)gbuf;
+  for (int i = 0; i < d->n_layers; ++i) {
+    a.sv_c[i] = d->sv_c[i]; a.sv_z[i] = d->sv_z[i]; a.sv_s[i] = d->sv_s[i];
+    a.gb_z[i] = d->gb_z[i]; a.gb_s[i] = d->gb_s[i]; a.gb_t[i] = d->gb_t[i];
+    a.off_b[i] = d->off_b[i]; a.off_bl[i] = d->off_bl[i];
+  }
+  a.off_w0 = d->off_w[0];
+  a.gp = gp; a.wgrads = wgrads ? 1 : 0; a.dcoords = dcoords;
+  a.mod_mask = d->modulated_mask; a.n_layers = d->n_layers; a.in_dim = d->in_dim; a.H = d->hidden; a.HP = d->HP;
+  a.out_dim = d->out_dim; a.xsteps = ksteps(d->HP); a.xrow = 64 * a.xsteps;
+  a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
+  const int smem = FUSED_TS * a.xrow + 20 * d->HP * 4 + FUSED_TS * 64 + FUSED_TS * 16;
+  CINEMA_REQUIRE(smem <= 160 * 1024, "fused_backward_chain: LDS budget exceeded (%d bytes)", smem);
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_smem = smem;
+  }
+  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(Npad / FUSED_TS)), dim3(512), smem, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

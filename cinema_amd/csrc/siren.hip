@@ -4,6 +4,7 @@
 #include "fused.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -764,7 +765,10 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     CINEMA_CHECK_HIP(hipMemsetAsync(dcoords, 0, sizeof(float) * (size_t)Npad * d->in_dim, s));
 
   // ---- chain ----
-  for (int i = nl - 1; i >= 0 && (phases & CINEMA_BWD_PHASE_CHAIN); --i) {
+  const bool fused_chain = std::is_same<T, bf16_t>::value && fused_mode(d) == 64;
+  if (fused_chain && (phases & CINEMA_BWD_PHASE_CHAIN))
+    if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s)) return rc;
+  for (int i = nl - 1; i >= 0 && (phases & CINEMA_BWD_PHASE_CHAIN) && !fused_chain; --i) {
     const bool mod = (d->modulated_mask >> i) & 1u;
     const bool top = i == nl - 1, first = i == 0;
     BwdArgs a = {};
