@@ -48,16 +48,20 @@ void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
   for (int i = d->n_layers - 2; i >= 0; --i) plan_add(p, d->off_w[i + 1], H, H, H, 1, ksteps(d->HP));
 }
 
-struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg, steps, nslab; const float *params; bf16_t *dst; };
+// two streams (forward, backward chain) packed by one launch: segments [0, nseg0) belong to stream 0
+struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1; };
 
 __global__ void k_pack_stream(PackStreamArgs a) {
-  const long nchunk = (long)a.nslab * a.steps * 256;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += (long)gridDim.x * blockDim.x) {
+  const long n0 = (long)a.nslab * a.steps0 * 256, nchunk = n0 + (long)a.nslab * a.steps1 * 256;
+  for (long qq = (long)blockIdx.x * blockDim.x + threadIdx.x; qq < nchunk; qq += (long)gridDim.x * blockDim.x) {
+    const bool second = qq >= n0;
+    const long q = second ? qq - n0 : qq;
+    const int steps = second ? a.steps1 : a.steps0, sbeg = second ? a.nseg0 : 0, send = second ? a.nseg0 + a.nseg1 : a.nseg0;
     const int lane = (int)(q & 63), ft = (int)((q >> 6) & 3);
     const long sq = q >> 8;
-    const int step = (int)(sq % a.steps), slab = (int)(sq / a.steps);
-    int si = 0;
-    while (si + 1 < a.nseg && step >= a.seg[si + 1].step0) ++si;
+    const int step = (int)(sq % steps), slab = (int)(sq / steps);
+    int si = sbeg;
+    while (si + 1 < send && step >= a.seg[si + 1].step0) ++si;
     const Seg sg = a.seg[si];
     const int kk = step - sg.step0, i = lane & 15, gk = lane >> 4;
     const int feat = slab * 64 + 16 * (i >> 2) + 4 * ft + (i & 3);
@@ -71,7 +75,7 @@ __global__ void k_pack_stream(PackStreamArgs a) {
       if (feat < sg.rows && k < sg.cols) x = sg.transpose ? src[(long)k * sg.ld + feat] : src[(long)feat * sg.ld + k];
       v[j] = (bf16_t)x;
     }
-    *reinterpret_cast<bf16x8 *>(a.dst + q * 8) = v;
+    *reinterpret_cast<bf16x8 *>((second ? a.dst1 : a.dst0) + q * 8) = v;
   }
 }
 
@@ -641,19 +645,23 @@ void fused_plan(cinema_siren_desc *d, long *pk) {
 
 int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
   if (d->pk_fs < 0) return 0;
-  for (int which = 0; which < 2; ++which) {
-    StreamPlan p;
-    if (which == 0) plan_fwd_stream(d, p); else plan_bwd_stream(d, p);
-    if (p.steps == 0) continue;
+  {
+    StreamPlan p0, p1;
+    plan_fwd_stream(d, p0);
+    plan_bwd_stream(d, p1);
     PackStreamArgs a;
-    for (int k = 0; k < p.nseg; ++k) a.seg[k] = p.seg[k];
-    a.nseg = p.nseg; a.steps = p.steps; a.nslab = d->HP / 64;
+    CINEMA_REQUIRE(p0.nseg + p1.nseg <= FUSED_MAX_SEGS, "fused_pack: %d segments exceed the table", p0.nseg + p1.nseg);
+    for (int k = 0; k < p0.nseg; ++k) a.seg[k] = p0.seg[k];
+    for (int k = 0; k < p1.nseg; ++k) a.seg[p0.nseg + k] = p1.seg[k];
+    a.nseg0 = p0.nseg; a.nseg1 = p1.nseg; a.steps0 = p0.steps; a.steps1 = p1.steps; a.nslab = d->HP / 64;
     a.params = params;
-    a.dst = (bf16_t *)packed + (which == 0 ? d->pk_fs : d->pk_bs);
-    const long nchunk = (long)a.nslab * a.steps * 256;
-    const int grid = (int)std::min<long>((nchunk + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
-    CINEMA_CHECK_HIP(hipGetLastError());
+    a.dst0 = (bf16_t *)packed + d->pk_fs; a.dst1 = (bf16_t *)packed + d->pk_bs;
+    const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
+    if (nchunk > 0) {
+      const int grid = (int)std::min<long>((nchunk + 255) / 256, 4096);
+      hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
+      CINEMA_CHECK_HIP(hipGetLastError());
+    }
   }
   PackSideArgs b = {};
   b.params = params; b.dst = (float *)((bf16_t *)packed + d->pk_side);

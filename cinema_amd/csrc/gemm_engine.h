@@ -283,25 +283,86 @@ __device__ __forceinline__ void nt_mainloop(f32x4 (&acc)[4][4], const T *A, int 
   }
 }
 
+// acc += sum over segments s of A_s[f0.., :K_s] * B_s[n0.., :K_s]^T: ONE pipeline over the k-tiles of all segments
+// (two register stages, loads issued two tiles ahead, crossing segment boundaries), so a chain of short GEMMs that
+// accumulate into the same tile pays one prologue instead of one per segment.
+struct NtSeg { const void *A; const void *B; int K; };   // A: packed [rowsA x K] (ld = K), B: [rows x ldB]
+
+template <typename T>
+__device__ __forceinline__ void nt_mainloop_segs(f32x4 (&acc)[4][4], const NtSeg *segs, int nseg, int f0, int rowsA,
+                                                 long n0, int ldB, char *smem) {
+  using E = Engine<T>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wf = wave >> 1, wn = wave & 1;
+  lds_char *base = (lds_char *)smem;
+  typename E::Stage s0, s1;
+  int nt = 0;
+  for (int s = 0; s < nseg; ++s) nt += segs[s].K / E::BK;
+  if (nt == 0) return;
+  int ls = 0, lk = 0;   // cursor of the next tile to load
+  auto load_next = [&](typename E::Stage &st) {
+    const NtSeg sg = segs[ls];
+    E::nt_load(st, (const T *)sg.A + (size_t)f0 * sg.K, sg.K, rowsA - f0, (const T *)sg.B + (size_t)n0 * ldB, ldB, lk, tid);
+    lk += E::BK;
+    if (lk >= sg.K) { lk = 0; ++ls; }
+  };
+  __syncthreads();  // LDS may still be read by a previous mainloop of this workgroup
+  load_next(s0);
+  if (nt > 1) load_next(s1);
+  E::nt_store(s0, base, base + E::NT_TILE, tid);
+  __syncthreads();
+#define NT_ITER(SFREE, SNEXT, CUR)                                                                            \
+  {                                                                                                           \
+    if (t + 2 < nt) load_next(SFREE);                                                                         \
+    E::nt_compute(acc, base + (CUR) * 2 * E::NT_TILE, base + (CUR) * 2 * E::NT_TILE + E::NT_TILE, wf, wn, lane); \
+    if (t + 1 < nt)                                                                                           \
+      E::nt_store(SNEXT, base + ((CUR) ^ 1) * 2 * E::NT_TILE, base + ((CUR) ^ 1) * 2 * E::NT_TILE + E::NT_TILE, tid); \
+    __syncthreads();                                                                                          \
+  }
+  int t = 0;
+  while (true) {
+    NT_ITER(s0, s1, 0)
+    if (++t >= nt) break;
+    NT_ITER(s1, s0, 1)
+    if (++t >= nt) break;
+  }
+#undef NT_ITER
+}
+
 // acc += P[nbeg..nend, h0..]^T * Q[nbeg..nend, c0..]; nbeg/nend multiples of Engine::BN.
+// Two register stages: the loads of n-tile t+2 are issued while tile t is being multiplied and tile t+1 waits in the
+// other stage, so every global load has two full iterations to land (one stage leaves these kernels latency-bound:
+// about one n-tile per HBM round trip and workgroup).
 template <typename T>
 __device__ __forceinline__ void tn_mainloop(f32x4 (&acc)[4][4], const T *P, int ldP, int h0, const T *Q, int ldQ,
                                             int c0, int nbeg, int nend, int nht, char *smem) {
   using E = Engine<T>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wh = wave >> 1, wk = wave & 1;
   lds_char *base = (lds_char *)smem;
-  typename E::Stage st;
+  typename E::Stage s0, s1;
   if (nbeg >= nend) return;  // uniform per workgroup
-  E::tn_load(st, P, ldP, h0, Q, ldQ, c0, nbeg, tid);
-  E::tn_store(st, base, base + E::TN_TILE, tid);
+  const int last = nend - E::BN;
+  E::tn_load(s0, P, ldP, h0, Q, ldQ, c0, nbeg, tid);
+  E::tn_load(s1, P, ldP, h0, Q, ldQ, c0, nbeg + E::BN <= last ? nbeg + E::BN : last, tid);
+  E::tn_store(s0, base, base + E::TN_TILE, tid);
   __syncthreads();
-  int cur = 0;
-  for (int n0 = nbeg; n0 < nend; n0 += E::BN) {
-    const bool more = n0 + E::BN < nend;
-    if (more) E::tn_load(st, P, ldP, h0, Q, ldQ, c0, n0 + E::BN, tid);
-    E::tn_compute(acc, base + cur * 2 * E::TN_TILE, base + cur * 2 * E::TN_TILE + E::TN_TILE, wh, wk, lane, nht);
-    if (more) E::tn_store(st, base + (cur ^ 1) * 2 * E::TN_TILE, base + (cur ^ 1) * 2 * E::TN_TILE + E::TN_TILE, tid);
-    __syncthreads();
-    cur ^= 1;
+  // tile t sits in LDS buffer (t & 1); stage s_(t & 1) is free, stage s_((t + 1) & 1) holds tile t + 1
+#define TN_ITER(SFREE, SNEXT, CUR)                                                                            \
+  {                                                                                                           \
+    const int n2_ = n0 + 2 * E::BN;                                                                           \
+    E::tn_load(SFREE, P, ldP, h0, Q, ldQ, c0, n2_ <= last ? n2_ : last, tid);                                 \
+    E::tn_compute(acc, base + (CUR) * 2 * E::TN_TILE, base + (CUR) * 2 * E::TN_TILE + E::TN_TILE, wh, wk, lane, nht); \
+    if (n0 + E::BN < nend)                                                                                    \
+      E::tn_store(SNEXT, base + ((CUR) ^ 1) * 2 * E::TN_TILE, base + ((CUR) ^ 1) * 2 * E::TN_TILE + E::TN_TILE, tid); \
+    __syncthreads();                                                                                          \
   }
+  int n0 = nbeg;
+  while (true) {
+    TN_ITER(s0, s1, 0)
+    n0 += E::BN;
+    if (n0 >= nend) break;
+    TN_ITER(s1, s0, 1)
+    n0 += E::BN;
+    if (n0 >= nend) break;
+  }
+#undef TN_ITER
 }

@@ -293,9 +293,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_layer_bwd(BwdArgs a) {
 // ----------------------------------------------------------------------------------------
 // d lat = sum over modulated layers (ds * Wl_scale + dt * Wl_shift) + dOut * Wf[:, H:]
 // ----------------------------------------------------------------------------------------
-struct DlatSeg { const void *Wt; const void *G; int K; };
 struct DlatArgs {
-  DlatSeg seg[2 * CINEMA_MAX_LAYERS];
+  NtSeg seg[2 * CINEMA_MAX_LAYERS];
   int nseg;
   const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;
   int lat; int LP; int ldg;
@@ -314,11 +313,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
     acc_fill(acc, zero);
   }
   smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
-  for (int s = 0; s < a.nseg; ++s) {
-    const DlatSeg sg = a.seg[s];
-    nt_mainloop<T>(acc, (const T *)sg.Wt + (size_t)c.f0 * sg.K, sg.K, a.LP - c.f0, (const T *)sg.G + (size_t)c.n0 * a.ldg,
-                   a.ldg, sg.K, smem);
-  }
+  nt_mainloop_segs<T>(acc, a.seg, a.nseg, c.f0, a.LP, c.n0, a.ldg, smem);
   if (c.fb < a.LP) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -601,13 +596,14 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
     a.job[nj++] = j;
     return nj == PACK_MAX_JOBS ? flush() : 0;
   };
-  // the row-major forward copies are only read by the layer-by-layer forward kernels
+  // W, W^T and the row-major linear_lats copies are only read by the layer-by-layer kernels
   const bool fwd_layered = fused_mode(d) == 0;
   for (int i = 0; i < d->n_layers; ++i) {
     if (i > 0) {
-      if (fwd_layered)
+      if (fwd_layered) {   // the fused chain kernels read the weight streams instead
         if (int rc = add(params + d->off_w[i], d->pk_w[i], H, H, H, HP, HP, 0)) return rc;
-      if (int rc = add(params + d->off_w[i], d->pk_wt[i], H, H, H, HP, HP, 1)) return rc;
+        if (int rc = add(params + d->off_w[i], d->pk_wt[i], H, H, H, HP, HP, 1)) return rc;
+      }
     }
     if ((d->modulated_mask >> i) & 1u) {
       const float *wl = params + d->off_wl[i];
@@ -619,24 +615,14 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
       if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
     }
   }
-  if (int rc = flush()) return rc;
-  // final linear: 2 jobs per output row group via a second launch with row-strided destinations
-  PackArgs b;
-  int nb = 0;
+  // final linear: one job per (output row, x | lat part), padded to 16 rows
   for (int o = 0; o < 16; ++o) {
     const bool live = o < d->out_dim;
-    PackJob j1 = {params + d->off_wf + (size_t)(live ? o : 0) * (H + L), d->pk_wf + (long)o * (HP + LP), live ? 1 : 0, H,
-                  H + L, 1, HP, 0};
-    PackJob j2 = {params + d->off_wf + (size_t)(live ? o : 0) * (H + L) + H, d->pk_wf + (long)o * (HP + LP) + HP,
-                  live ? 1 : 0, L, H + L, 1, LP, 0};
-    b.job[nb++] = j1;
-    b.job[nb++] = j2;
+    const float *row = params + d->off_wf + (size_t)(live ? o : 0) * (H + L);
+    if (int rc = add(row, d->pk_wf + (long)o * (HP + LP), live ? 1 : 0, H, H + L, 1, HP, 0)) return rc;
+    if (int rc = add(row + H, d->pk_wf + (long)o * (HP + LP) + HP, live ? 1 : 0, L, H + L, 1, LP, 0)) return rc;
   }
-  b.njobs = nb;
-  b.packed = packed;
-  dim3 grid2(1, nb);
-  hipLaunchKernelGGL((k_pack<T>), grid2, dim3(256), 0, s, b);
-  CINEMA_CHECK_HIP(hipGetLastError());
+  if (int rc = flush()) return rc;
   return fwd_layered ? 0 : fused_pack(d, params, packed, s);
 }
 
@@ -816,8 +802,8 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     int ns = 0;
     for (int i = 0; i < nl; ++i)
       if ((d->modulated_mask >> i) & 1u) {
-        a.seg[ns].Wt = pk + d->pk_wlsT[i]; a.seg[ns].G = gb + slot * d->gb_s[i]; a.seg[ns].K = HP; ++ns;
-        a.seg[ns].Wt = pk + d->pk_wltT[i]; a.seg[ns].G = gb + slot * d->gb_t[i]; a.seg[ns].K = HP; ++ns;
+        a.seg[ns].A = pk + d->pk_wlsT[i]; a.seg[ns].B = gb + slot * d->gb_s[i]; a.seg[ns].K = HP; ++ns;
+        a.seg[ns].A = pk + d->pk_wltT[i]; a.seg[ns].B = gb + slot * d->gb_t[i]; a.seg[ns].K = HP; ++ns;
       }
     a.nseg = ns;
     a.Xs = dout; a.ldxs = d->out_dim; a.ks = d->out_dim;

@@ -398,6 +398,44 @@ __global__ __launch_bounds__(256) void k_fill(const int32_t *idx, long N, long S
   }
 }
 
+// The same grouping in ONE launch of one workgroup, for the batch sizes of a training step (N <= GROUP_SMALL_MAX,
+// S <= GROUP_LDS_BINS): histogram, exclusive scan and fill all live in LDS, no memset / scan / fill launches.
+#define GROUP_SMALL_MAX 65536
+__global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N, long S, int32_t *offsets, int32_t *perm) {
+  __shared__ int32_t bins[GROUP_LDS_BINS];
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < S; b += 1024) bins[b] = 0;
+  __syncthreads();
+  for (long n = tid; n < N; n += 1024) atomicAdd(bins + clamp_subject(idx[n], S), 1);
+  __syncthreads();
+  // exclusive scan of bins[0..S): each thread owns a contiguous run of ceil(S/1024) bins
+  const int per = (int)((S + 1023) / 1024);
+  const int b0 = tid * per;
+  int local = 0;
+  for (int k = 0; k < per; ++k)
+    if (b0 + k < S) local += bins[b0 + k];
+  part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int t = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += t;
+    __syncthreads();
+  }
+  int run = part[tid] - local;
+  for (int k = 0; k < per; ++k)
+    if (b0 + k < S) {
+      const int c = bins[b0 + k];
+      offsets[b0 + k] = run;
+      bins[b0 + k] = run;      // becomes the fill cursor
+      run += c;
+    }
+  if (tid == 1023) offsets[S] = part[1023];
+  __syncthreads();
+  for (long n = tid; n < N; n += 1024) perm[atomicAdd(bins + clamp_subject(idx[n], S), 1)] = (int32_t)n;
+}
+
 // per-subject sum of the per-sample embedding gradients (table mode): one wave per subject, fixed order
 __global__ __launch_bounds__(256) void k_tf_reduce(const int32_t *offsets, const int32_t *perm, const float *dtf_ps, int dim,
                                                    long S, float *dembed) {
@@ -580,11 +618,15 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
   int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
   if (dlatents != nullptr || table_tf) {
     CINEMA_REQUIRE(work != nullptr, "cinema_affine_trilerp_bwd: work buffer required");
-    CINEMA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)S, s));
-    const unsigned g1 = (unsigned)std::min<long>((N + 1023) / 1024, 512);
-    hipLaunchKernelGGL(k_hist, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, counts);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, (long)S, offsets);
-    hipLaunchKernelGGL(k_fill, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, offsets, counts, perm);
+    if (N <= GROUP_SMALL_MAX && S <= GROUP_LDS_BINS) {
+      hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, s, idx, (long)N, (long)S, offsets, perm);
+    } else {
+      CINEMA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)S, s));
+      const unsigned g1 = (unsigned)std::min<long>((N + 1023) / 1024, 512);
+      hipLaunchKernelGGL(k_hist, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, counts);
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, (long)S, offsets);
+      hipLaunchKernelGGL(k_fill, dim3(g1), dim3(256), 0, s, idx, (long)N, (long)S, offsets, counts, perm);
+    }
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   if (dembed != nullptr) {

@@ -109,9 +109,14 @@ class HotPathTrainer:
             groups.append({"params": [self.tfs], "lr": o["lr_tf"], "weight_decay": o["tf_weight_decay"]})
         if self.cond_param is not None:
             groups.append({"params": [self.cond_param], "lr": o["lr_latent"], "weight_decay": o["latent_weight_decay"]})
-        self.opt_local = HipAdamW(groups)
-        self.opt_mlp = (HipAdamW([{"params": [self.flat_param], "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}])
-                        if self.train_mlp else None)
+        mlp_group = {"params": [self.flat_param], "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}
+        if self.train_mlp and self.world == 1:
+            # one process: nothing to wait for between the table-side and the MLP update -> one launch for all groups
+            self.opt_local = HipAdamW(groups + [mlp_group])
+            self.opt_mlp = None
+        else:
+            self.opt_local = HipAdamW(groups)
+            self.opt_mlp = HipAdamW([mlp_group]) if self.train_mlp else None
         self.schedulers = []
         if o.get("scheduler", {}).get("type") == "cosine":
             T = args["epochs"][split]

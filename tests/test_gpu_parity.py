@@ -218,6 +218,14 @@ def test_oracle_parity_dhcp_shape_tf_table(precision):
     assert not bad, f"{bad}\nall: {errs}"
 
 
+def test_oracle_parity_large_batch_grouping_path():
+    """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
+    errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,
+                        seed=19, precision="fp32", tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < 2e-4)}     # sums over 10^4 samples per subject in fp32
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_tiny_batch_and_single_sample():
     """N = 1 and N = 3 (far below one tile): shapes stay (N, out) and values match the oracle."""
     for n in (1, 3):
