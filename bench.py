@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0               # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what streaming kernels reach
 
 
 def make_args(hidden, precision, loss_metric, n_samples):
@@ -144,29 +145,47 @@ def main():
         elapsed = float(t.item())
     losses = trainer.loss_dict()
 
-    # ---- roofline of the dominant kernel: the grouped weight-gradient GEMM, timed alone on its launch stream
+    # ---- roofline of the dominant kernel, timed alone with events on its launch stream.  By time (profiles/) that is the
+    # fused backward chain k_fused_bwd: per sample it reads the saved c of every sine layer and z, s of the modulated
+    # ones and writes dz of every layer and ds, dt of the modulated ones, HP bf16 values each; its MFMA work
+    # (2*H*H*(L) FLOP per sample) would take a third of that at peak, so HBM is the roofline that binds it.
     roofline = None
+    others = []
     if rank == 0:
         from cinema_amd import _lib
         eng = trainer.eng
         ws = eng.ws
         reps = opt.kernel_reps
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW)
-        ev1.record()
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / reps
         d = eng.desc
-        macs = n * (5 * d.hidden * d.hidden + 3 * 2 * d.hidden * d.lat)           # dW of 5 linear + 3 linear_lats
+        esize = 2 if opt.precision == "bf16" else 4
+
+        def time_phase(phase):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eng.backward(n, ws.dout, weight_grads=True, phases=phase)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(reps):
+                eng.backward(n, ws.dout, weight_grads=True, phases=phase)
+            ev1.record()
+            torch.cuda.synchronize()
+            return ev0.elapsed_time(ev1) / reps
+
+        n_mod = bin(d.modulated_mask).count("1")
+        ms = time_phase(_lib.BWD_PHASE_CHAIN)
+        tensors = 2 * d.n_layers + 4 * n_mod                       # c + dz per layer, z, s, ds, dt per modulated layer
+        bytes_per_sample = tensors * d.HP * esize + 4 * (d.out_dim + 2 * d.in_dim)
+        ach = n * bytes_per_sample / (ms * 1e-3) / 1e9
+        kname = ("k_fused_bwd (backward chain of the SIREN stack, one launch)" if opt.precision == "bf16"
+                 else "k_layer_bwd x layers (backward chain, fp32 layer-by-layer kernels)")
+        roofline = {"kernel": kname, "bound": "hbm",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": ms, "bytes_per_launch": n * bytes_per_sample}
         peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-        ach = 2.0 * macs / (ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_dw_grouped (all weight-gradient GEMMs of one step, one launch)", "bound": "mfma",
-                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                    "avg_launch_ms": ms, "flops_per_launch": 2.0 * macs}
+        ms_dw = time_phase(_lib.BWD_PHASE_DW)
+        macs = n * (5 * d.hidden * d.hidden + 3 * 2 * d.hidden * d.lat)           # dW of 5 linear + 3 linear_lats
+        others.append({"kernel": "k_dw_grouped (all weight-gradient GEMMs, one launch)", "bound": "mfma",
+                       "achieved": 2.0 * macs / (ms_dw * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                       "frac": 2.0 * macs / (ms_dw * 1e-3) / 1e12 / peak, "avg_launch_ms": ms_dw})
 
     fwd_f, tot_f = flops_per_sample()
     value = world * opt.steps * n / elapsed
@@ -185,6 +204,7 @@ def main():
     }
     if rank == 0:
         res["roofline"] = roofline
+        res["roofline_other_kernels"] = others
         if world == 1 and not opt.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, n, opt.subjects)
         print(json.dumps(res))

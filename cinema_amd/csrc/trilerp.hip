@@ -400,14 +400,23 @@ __global__ __launch_bounds__(256) void k_fill(const int32_t *idx, long N, long S
 
 // The same grouping in ONE launch of one workgroup, for the batch sizes of a training step (N <= GROUP_SMALL_MAX,
 // S <= GROUP_LDS_BINS): histogram, exclusive scan and fill all live in LDS, no memset / scan / fill launches.
-#define GROUP_SMALL_MAX 65536
+#define GROUP_SMALL_MAX 32768
 __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N, long S, int32_t *offsets, int32_t *perm) {
   __shared__ int32_t bins[GROUP_LDS_BINS];
   __shared__ int32_t part[1024];
   const int tid = threadIdx.x;
   for (int b = tid; b < S; b += 1024) bins[b] = 0;
   __syncthreads();
-  for (long n = tid; n < N; n += 1024) atomicAdd(bins + clamp_subject(idx[n], S), 1);
+  // the subject ids of this thread's samples are fetched in one batch (independent loads in flight together) and kept
+  int32_t mine[GROUP_SMALL_MAX / 1024];
+#pragma unroll
+  for (int k = 0; k < GROUP_SMALL_MAX / 1024; ++k) {
+    const long n = tid + 1024L * k;
+    mine[k] = n < N ? (int32_t)clamp_subject(idx[n], S) : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < GROUP_SMALL_MAX / 1024; ++k)
+    if (mine[k] >= 0) atomicAdd(bins + mine[k], 1);
   __syncthreads();
   // exclusive scan of bins[0..S): each thread owns a contiguous run of ceil(S/1024) bins
   const int per = (int)((S + 1023) / 1024);
@@ -433,7 +442,9 @@ __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N
     }
   if (tid == 1023) offsets[S] = part[1023];
   __syncthreads();
-  for (long n = tid; n < N; n += 1024) perm[atomicAdd(bins + clamp_subject(idx[n], S), 1)] = (int32_t)n;
+#pragma unroll
+  for (int k = 0; k < GROUP_SMALL_MAX / 1024; ++k)
+    if (mine[k] >= 0) perm[atomicAdd(bins + mine[k], 1)] = (int32_t)(tid + 1024 * k);
 }
 
 // per-subject sum of the per-sample embedding gradients (table mode): one wave per subject, fixed order
