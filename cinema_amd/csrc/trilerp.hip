@@ -399,14 +399,17 @@ __global__ __launch_bounds__(256) void k_fill(const int32_t *idx, long N, long S
 }
 
 // The same grouping in ONE launch of one workgroup, for the batch sizes of a training step (N <= GROUP_SMALL_MAX,
-// S <= GROUP_LDS_BINS): histogram, exclusive scan and fill all live in LDS, no memset / scan / fill launches.
+// S <= GROUP_SMALL_BINS): every wave keeps a private histogram in LDS (a shared one serialises: a step has ~400
+// samples per subject), the scan over (subject, wave) turns the counts into per-wave fill cursors, and the fill is
+// again wave-private.  No memset / scan / fill launches.
 #define GROUP_SMALL_MAX 32768
+#define GROUP_SMALL_BINS 512
 __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N, long S, int32_t *offsets, int32_t *perm) {
-  __shared__ int32_t bins[GROUP_LDS_BINS];
+  __shared__ int32_t bins[16 * GROUP_SMALL_BINS];   // [wave][subject]
   __shared__ int32_t part[1024];
-  const int tid = threadIdx.x;
-  for (int b = tid; b < S; b += 1024) bins[b] = 0;
-  __syncthreads();
+  const int tid = threadIdx.x, wave = tid >> 6;
+  int32_t *mybins = bins + wave * GROUP_SMALL_BINS;
+  for (int b = tid; b < 16 * GROUP_SMALL_BINS; b += 1024) bins[b] = 0;
   // the subject ids of this thread's samples are fetched in one batch (independent loads in flight together) and kept
   int32_t mine[GROUP_SMALL_MAX / 1024];
 #pragma unroll
@@ -414,17 +417,21 @@ __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N
     const long n = tid + 1024L * k;
     mine[k] = n < N ? (int32_t)clamp_subject(idx[n], S) : -1;
   }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < GROUP_SMALL_MAX / 1024; ++k)
-    if (mine[k] >= 0) atomicAdd(bins + mine[k], 1);
+    if (mine[k] >= 0) atomicAdd(mybins + mine[k], 1);
   __syncthreads();
-  // exclusive scan of bins[0..S): each thread owns a contiguous run of ceil(S/1024) bins
-  const int per = (int)((S + 1023) / 1024);
-  const int b0 = tid * per;
-  int local = 0;
-  for (int k = 0; k < per; ++k)
-    if (b0 + k < S) local += bins[b0 + k];
-  part[tid] = local;
+  // per subject: exclusive prefix over the 16 waves; subject totals go through a block scan
+  int total = 0;
+  if (tid < S) {
+    for (int w = 0; w < 16; ++w) {
+      const int c = bins[w * GROUP_SMALL_BINS + tid];
+      bins[w * GROUP_SMALL_BINS + tid] = total;
+      total += c;
+    }
+  }
+  part[tid] = total;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
     const int t = tid >= d ? part[tid - d] : 0;
@@ -432,19 +439,16 @@ __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N
     part[tid] += t;
     __syncthreads();
   }
-  int run = part[tid] - local;
-  for (int k = 0; k < per; ++k)
-    if (b0 + k < S) {
-      const int c = bins[b0 + k];
-      offsets[b0 + k] = run;
-      bins[b0 + k] = run;      // becomes the fill cursor
-      run += c;
-    }
+  if (tid < S) {
+    const int off = part[tid] - total;
+    offsets[tid] = off;
+    for (int w = 0; w < 16; ++w) bins[w * GROUP_SMALL_BINS + tid] += off;   // fill cursor of (wave, subject)
+  }
   if (tid == 1023) offsets[S] = part[1023];
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < GROUP_SMALL_MAX / 1024; ++k)
-    if (mine[k] >= 0) perm[atomicAdd(bins + mine[k], 1)] = (int32_t)(tid + 1024 * k);
+    if (mine[k] >= 0) perm[atomicAdd(mybins + mine[k], 1)] = (int32_t)(tid + 1024 * k);
 }
 
 // per-subject sum of the per-sample embedding gradients (table mode): one wave per subject, fixed order
@@ -629,7 +633,7 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
   int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
   if (dlatents != nullptr || table_tf) {
     CINEMA_REQUIRE(work != nullptr, "cinema_affine_trilerp_bwd: work buffer required");
-    if (N <= GROUP_SMALL_MAX && S <= GROUP_LDS_BINS) {
+    if (N <= GROUP_SMALL_MAX && S <= GROUP_SMALL_BINS) {
       hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, s, idx, (long)N, (long)S, offsets, perm);
     } else {
       CINEMA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)S, s));
