@@ -524,9 +524,10 @@ __device__ __forceinline__ void dense_axis(const Axis &a, float (&w)[LX > LY ? (
 
 #define LATRED_WAVES 8
 template <int LX, int LY, int LZ>
-__global__ __launch_bounds__(64 * LATRED_WAVES) void k_lat_reduce_dense(LatRedArgs a) {
+__global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedArgs a) {
   constexpr int G = LX * LY * LZ;
   constexpr int LM = LX > LY ? (LX > LZ ? LX : LZ) : (LY > LZ ? LY : LZ);
+  // 2 * LATRED_WAVES waves walk the subject's samples; the upper half folds its sums into the lower half's LDS slots
   __shared__ float part[LATRED_WAVES][G][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long s = blockIdx.x;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64 * LATRED_WAVES) void k_lat_reduce_dense(LatRedAr
   for (int k = 0; k < G; ++k) acc[k] = 0.f;
   // no store inside the loop: the unrolled iterations' dependent loads (perm -> coords, dlat) overlap
 #pragma unroll 4
-  for (int p = beg + wave; p < end; p += LATRED_WAVES) {
+  for (int p = beg + wave; p < end; p += 2 * LATRED_WAVES) {
     const long n = a.perm[p];
     const Axis az = axis_nodes(a.coords_t[n * 3], LZ), ay = axis_nodes(a.coords_t[n * 3 + 1], LY),
                ax = axis_nodes(a.coords_t[n * 3 + 2], LX);
@@ -557,10 +558,17 @@ __global__ __launch_bounds__(64 * LATRED_WAVES) void k_lat_reduce_dense(LatRedAr
       }
     }
   }
+  if (wave < LATRED_WAVES) {
 #pragma unroll
-  for (int k = 0; k < G; ++k) part[wave][k][lane] = acc[k];
+    for (int k = 0; k < G; ++k) part[wave][k][lane] = acc[k];
+  }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * G; e += 64 * LATRED_WAVES) {
+  if (wave >= LATRED_WAVES) {
+#pragma unroll
+    for (int k = 0; k < G; ++k) part[wave - LATRED_WAVES][k][lane] += acc[k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * G; e += 128 * LATRED_WAVES) {
     const int cc = e / G, nd = e - cc * G;
     if (c0 + cc < a.C) {
       float t = 0.f;
@@ -661,9 +669,9 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
     CINEMA_REQUIRE(S <= 0x7fffffff && (C + 63) / 64 <= 65535, "grid too large");
     LatRedArgs a = {offsets, perm, coords_t, dlat, C, lx, ly, lz, LP, dlatents};
     const dim3 grid((unsigned)S, (C + 63) / 64);
-    if (lx == 3 && ly == 3 && lz == 3) hipLaunchKernelGGL((k_lat_reduce_dense<3, 3, 3>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
-    else if (lx == 1 && ly == 1 && lz == 1) hipLaunchKernelGGL((k_lat_reduce_dense<1, 1, 1>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
-    else if (lx == 2 && ly == 2 && lz == 2) hipLaunchKernelGGL((k_lat_reduce_dense<2, 2, 2>), grid, dim3(64 * LATRED_WAVES), 0, s, a);
+    if (lx == 3 && ly == 3 && lz == 3) hipLaunchKernelGGL((k_lat_reduce_dense<3, 3, 3>), grid, dim3(128 * LATRED_WAVES), 0, s, a);
+    else if (lx == 1 && ly == 1 && lz == 1) hipLaunchKernelGGL((k_lat_reduce_dense<1, 1, 1>), grid, dim3(128 * LATRED_WAVES), 0, s, a);
+    else if (lx == 2 && ly == 2 && lz == 2) hipLaunchKernelGGL((k_lat_reduce_dense<2, 2, 2>), grid, dim3(128 * LATRED_WAVES), 0, s, a);
     else hipLaunchKernelGGL(k_lat_reduce, grid, dim3(256), smem, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }

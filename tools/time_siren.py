@@ -39,3 +39,4 @@ timeit("backward: chain", lambda: eng.backward(N, ws.dout, weight_grads=True, ph
 timeit("backward: dlat", lambda: eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DLAT))
 timeit("backward: dW grouped", lambda: eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW))
 timeit("backward: all", lambda: eng.backward(N, ws.dout, weight_grads=True))
+timeit("backward: chain, frozen weights", lambda: eng.backward(N, ws.dout, weight_grads=False, phases=_lib.BWD_PHASE_CHAIN))
