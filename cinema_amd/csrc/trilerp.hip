@@ -115,24 +115,9 @@ __global__ void k_affine_from_embed(const float *embed, long rows, int dim, floa
 }
 
 // d embed from d coords_t:  coords_t = A c + t
-__global__ void k_affine_bwd(const float *coords, const int32_t *idx, const float *embed, int dim, int per_sample,
-                             const float *dct, long N, long S, float *dembed) {
-  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  long row = n;
-  if (!per_sample) {
-    long s = idx[n];
-    row = s < 0 ? 0 : (s >= S ? S - 1 : s);
-  }
-  float e[12];
-  for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[row * dim + k] : 0.f;
-  const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
-  const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
-  M3 G;  // dL/dA
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) G.m[i][j] = d[i] * c[j];
+// gradient of the loss w.r.t. one embedding row e from G = dL/dA (3x3) and d = dL/dt: every component is LINEAR in
+// (G, d), so a subject's table row needs only the sums of d c^T and d over its samples (k_tf_table_bwd)
+__device__ __forceinline__ void embed_grad(const float (&e)[12], int dim, const M3 &G, const float (&d)[3], float (&g)[12]) {
   float s1, c1, s2, c2, s3, c3;
   sincosf(e[0], &s1, &c1);
   sincosf(e[1], &s2, &c2);
@@ -142,7 +127,6 @@ __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const floa
   M3 D = m3_identity(), Sh = m3_identity(), sx = m3_identity(), sy = m3_identity(), sz = m3_identity();
   if (dim >= 9) { D.m[0][0] = 1.f + e[6]; D.m[1][1] = 1.f + e[7]; D.m[2][2] = 1.f + e[8]; }
   if (dim == 12) { shear_mats(e, sx, sy, sz); Sh = m3_mul(m3_mul(sx, sy), sz); }
-  float g[12];
   // rotation angles: <G (D Sh)^T, dR/dtheta>
   const M3 GR = m3_mul(G, m3_t(m3_mul(D, Sh)));
   g[0] = m3_dot(GR, m3_mul(m3_mul(drot_z(c1, s1), Rx2), Rz3));
@@ -162,7 +146,29 @@ __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const floa
     g[10] = gsx.m[0][1] + gsz.m[2][1];
     g[11] = gsx.m[0][2] + gsy.m[1][2];
   }
-  // always one row per sample; in table mode k_tf_reduce sums the rows of each subject afterwards
+}
+
+__global__ void k_affine_bwd(const float *coords, const int32_t *idx, const float *embed, int dim, int per_sample,
+                             const float *dct, long N, long S, float *dembed) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  long row = n;
+  if (!per_sample) {
+    long s = idx[n];
+    row = s < 0 ? 0 : (s >= S ? S - 1 : s);
+  }
+  float e[12];
+  for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[row * dim + k] : 0.f;
+  const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
+  const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
+  M3 G;  // dL/dA
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G.m[i][j] = d[i] * c[j];
+  float g[12];
+  embed_grad(e, dim, G, d, g);
+  // one row per sample (the table mode has its own kernel, k_tf_table_bwd)
   for (int k = 0; k < dim; ++k) dembed[n * dim + k] = g[k];
 }
 
@@ -451,28 +457,50 @@ __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N
     if (mine[k] >= 0) perm[atomicAdd(mybins + mine[k], 1)] = (int32_t)(tid + 1024 * k);
 }
 
-// per-subject sum of the per-sample embedding gradients (table mode): one wave per subject, fixed order
-__global__ __launch_bounds__(256) void k_tf_reduce(const int32_t *offsets, const int32_t *perm, const float *dtf_ps, int dim,
-                                                   long S, float *dembed) {
-  const int lane = threadIdx.x & 63;
-  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= S) return;
+// Table mode, one block per subject: sum d c^T and d over the subject's samples (embed_grad is linear in them), then
+// ONE evaluation of the embedding gradient per subject.  Replaces the per-sample rows + their per-subject reduction.
+__global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, const int32_t *perm, const float *coords,
+                                                      const float *dct, const float *embed, int dim, float *dembed) {
+  __shared__ float red[4][12];
+  const long s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-  for (int p = offsets[s] + lane; p < offsets[s + 1]; p += 64) {
-    const float *r = dtf_ps + (long)perm[p] * dim;
+#pragma unroll 2
+  for (int p = offsets[s] + tid; p < offsets[s + 1]; p += 256) {
+    const long n = perm[p];
+    const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
+    const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-      if (k < dim) acc[k] += r[k];
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i * 3 + j] += d[i] * c[j];
+      acc[9 + i] += d[i];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
-    if (lane == 0 && k < dim) dembed[s * dim + k] = acc[k];
+    if (lane == 0) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    M3 G;
+    float d[3], e[12], g[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) G.m[i][j] = red[0][i * 3 + j] + red[1][i * 3 + j] + red[2][i * 3 + j] + red[3][i * 3 + j];
+      d[i] = red[0][9 + i] + red[1][9 + i] + red[2][9 + i] + red[3][9 + i];
+    }
+    for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[s * dim + k] : 0.f;
+    embed_grad(e, dim, G, d, g);
+    for (int k = 0; k < dim; ++k) dembed[s * dim + k] = g[k];
   }
 }
+
 
 // d latents: one workgroup per (subject, 64-channel slice); the subject's samples are summed in LDS
 struct LatRedArgs {
@@ -655,12 +683,12 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
   if (dembed != nullptr) {
     CINEMA_REQUIRE(embed != nullptr, "dembed requested but embed is null");
     CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
-    float *per_sample_out = table_tf ? reinterpret_cast<float *>(work + 2 * S + 2 + N) : dembed;
-    hipLaunchKernelGGL(k_affine_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, idx, embed, tf_dim,
-                       embed_per_sample, dcoords_t, (long)N, (long)S, per_sample_out);
     if (table_tf)
-      hipLaunchKernelGGL(k_tf_reduce, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, s, offsets, perm, per_sample_out, tf_dim,
-                         (long)S, dembed);
+      hipLaunchKernelGGL(k_tf_table_bwd, dim3((unsigned)S), dim3(256), 0, s, offsets, perm, coords, dcoords_t, embed, tf_dim,
+                         dembed);
+    else
+      hipLaunchKernelGGL(k_affine_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, coords, idx, embed, tf_dim,
+                         embed_per_sample, dcoords_t, (long)N, (long)S, dembed);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   if (dlatents != nullptr) {
