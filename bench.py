@@ -115,7 +115,7 @@ def main():
     t0 = time.time()
     store = SubjectStore.synthetic(opt.subjects, (opt.grid,) * 3, spacing, [155, 155, 155], 2, 10, seed=42 + rank, device=dev)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
-    store.shuffle(gen)
+    store.shuffle(gen, group_chunk=opt.n_samples)     # as HotPathTrainer.epoch does: batches grouped by subject
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] synthetic store: {opt.subjects} subjects x {opt.grid}^3, {len(store):,} foreground samples/rank, "

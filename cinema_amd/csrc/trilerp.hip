@@ -276,11 +276,23 @@ struct TriBwdArgs {
   const int32_t *idx; const float *shadow; const float *coords_t; const float *dlat;
   long N, S; int C, lx, ly, lz, cond_dims, LP;
   float *dcoords_t; float *dcond;
+  int32_t *sorted_offsets;   // non-NULL: idx is non-decreasing, write offsets[0..S] (first sample of every subject)
 };
 
 __global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int G = a.lx * a.ly * a.lz;
+  if (a.sorted_offsets != nullptr) {
+    // batch already grouped by subject: the per-subject ranges are a lower_bound per subject (no counting sort)
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t <= a.S; t += (long)gridDim.x * blockDim.x) {
+      long lo = 0, hi = a.N;
+      while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (a.idx[mid] < t) lo = mid + 1; else hi = mid;
+      }
+      a.sorted_offsets[t] = (int32_t)(t == a.S ? a.N : lo);
+    }
+  }
   for (long n = (long)blockIdx.x * 4 + wave; n < a.N; n += (long)gridDim.x * 4) {
     const float t0 = a.coords_t[n * 3], t1 = a.coords_t[n * 3 + 1], t2 = a.coords_t[n * 3 + 2];
     long s = a.idx[n];
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, co
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
 #pragma unroll 2
   for (int p = offsets[s] + tid; p < offsets[s + 1]; p += 256) {
-    const long n = perm[p];
+    const long n = perm != nullptr ? perm[p] : p;
     const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
     const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
 #pragma unroll
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(256) void k_lat_reduce(LatRedArgs a) {
   const int c = c0 + lane;
   // generic grid: wave-private LDS table, plain read-modify-write (LDS float atomics serialise per lane: 3x slower)
   for (int p = beg + wave; p < end; p += 4) {
-    const long n = a.perm[p];
+    const long n = a.perm != nullptr ? a.perm[p] : p;
     const Axis az = axis_nodes(a.coords_t[n * 3], a.lz), ay = axis_nodes(a.coords_t[n * 3 + 1], a.ly),
                ax = axis_nodes(a.coords_t[n * 3 + 2], a.lx);
     int node[8]; float w[8];
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedA
   // no store inside the loop: the unrolled iterations' dependent loads (perm -> coords, dlat) overlap
 #pragma unroll 4
   for (int p = beg + wave; p < end; p += 2 * LATRED_WAVES) {
-    const long n = a.perm[p];
+    const long n = a.perm != nullptr ? a.perm[p] : p;
     const Axis az = axis_nodes(a.coords_t[n * 3], LZ), ay = axis_nodes(a.coords_t[n * 3 + 1], LY),
                ax = axis_nodes(a.coords_t[n * 3 + 2], LX);
     const float v = c < a.C ? a.dlat[n * a.LP + c] : 0.f;
@@ -647,11 +659,11 @@ extern "C" int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx
   return 0;
 }
 
-extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
-                                         int32_t embed_per_sample, const float *affine, const float *shadow,
-                                         const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
-                                         int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
-                                         float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream) {
+static int trilerp_bwd_impl(bool sorted, const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                            int32_t embed_per_sample, const float *affine, const float *shadow, const float *coords_t,
+                            const float *dlat, float *dcoords_t, int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx,
+                            int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP, float *dlatents, float *dembed,
+                            float *dcond, int32_t *work, void *stream) {
   (void)affine; (void)Npad;
   CINEMA_REQUIRE(coords && idx && coords_t && dcoords_t, "cinema_affine_trilerp_bwd: null argument");
   CINEMA_REQUIRE(dlat == nullptr || (shadow && work), "cinema_affine_trilerp_bwd: dlat given without shadow/work");
@@ -660,14 +672,17 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
   hipStream_t s = (hipStream_t)stream;
   const int G = lx * ly * lz;
   if (dlat != nullptr) {
-    TriBwdArgs a = {idx, shadow, coords_t, dlat, (long)N, (long)S, C, lx, ly, lz, cond_dims, LP, dcoords_t, dcond};
+    TriBwdArgs a = {idx, shadow, coords_t, dlat, (long)N, (long)S, C, lx, ly, lz, cond_dims, LP, dcoords_t, dcond,
+                    sorted ? work + S : nullptr};
     const unsigned grid = (unsigned)std::min<long>((N + 3) / 4, 8192);
     hipLaunchKernelGGL(k_trilerp_bwd_coord, dim3(grid), dim3(256), 0, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   const bool table_tf = dembed != nullptr && !embed_per_sample;
-  int32_t *counts = work, *offsets = work + S, *perm = work + 2 * S + 2;
-  if (dlatents != nullptr || table_tf) {
+  int32_t *counts = work, *offsets = work + S, *perm = sorted ? nullptr : work + 2 * S + 2;
+  CINEMA_REQUIRE(!sorted || (work != nullptr && dlat != nullptr),
+                 "cinema_affine_trilerp_bwd_sorted: needs dlat and the work buffer (offsets are written by the first kernel)");
+  if (!sorted && (dlatents != nullptr || table_tf)) {
     CINEMA_REQUIRE(work != nullptr, "cinema_affine_trilerp_bwd: work buffer required");
     if (N <= GROUP_SMALL_MAX && S <= GROUP_SMALL_BINS) {
       hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, s, idx, (long)N, (long)S, offsets, perm);
@@ -704,4 +719,23 @@ extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   return 0;
+}
+
+extern "C" int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                         int32_t embed_per_sample, const float *affine, const float *shadow,
+                                         const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
+                                         int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                                         float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream) {
+  return trilerp_bwd_impl(false, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
+                          Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream);
+}
+
+extern "C" int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                                int32_t embed_per_sample, const float *affine, const float *shadow,
+                                                const float *coords_t, const float *dlat, float *dcoords_t, int64_t N,
+                                                int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                                                int32_t cond_dims, int32_t LP, float *dlatents, float *dembed, float *dcond,
+                                                int32_t *work, void *stream) {
+  return trilerp_bwd_impl(true, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
+                          Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream);
 }

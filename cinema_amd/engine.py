@@ -202,8 +202,9 @@ def k1_forward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: to
 def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
                 cond_dims: int, tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int,
                 want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None,
-                dlat_out: Optional[torch.Tensor] = None):
-    """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords."""
+                dlat_out: Optional[torch.Tensor] = None, grouped: bool = False):
+    """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords.
+    grouped=True: the caller guarantees idx is non-decreasing (batch sorted by subject)."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents_shape
     need = 2 * S + 2 + 13 * n   # counts, offsets, perm, per-sample embedding gradients (fp32 x 12)
@@ -223,7 +224,8 @@ def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: t
             dtfs = torch.zeros(tfs.shape[0], tfs.shape[1], device=eng.device, dtype=torch.float32)
     dcond = torch.empty(n, cond_dims, device=eng.device, dtype=torch.float32) if (want_cond and cond_dims) else None
     npad = round_up(n, ROW_ALIGN)
-    check(lib.cinema_affine_trilerp_bwd(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
+    fn = lib.cinema_affine_trilerp_bwd_sorted if grouped else lib.cinema_affine_trilerp_bwd
+    check(fn(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
                                         1 if tf_per_sample else 0, ptr(st.affine) if tfs is not None else None,
                                         ptr(st.shadow), ptr(ws.coords_t), ptr(ws.dlat), ptr(ws.dcoords), n, npad, S, Cc,
                                         lx, ly, lz, cond_dims, d.LP, ptr(dlatents), ptr(dtfs), ptr(dcond), ptr(st.work),

@@ -37,16 +37,27 @@ class SubjectStore:
         self.intens, self.labels, self.V = intens, labels, int(voxels_per_subject)
         self.coords, self.voxel, self.subj = coords, voxel, subj
         self.conditions = conditions          # (S, cond_dims) normalised, or None
+        self.group_chunk = 0                  # > 0: every chunk of this many samples is sorted by subject
         self.n_subjects = labels.numel() // self.V
 
     def __len__(self):
         return self.coords.shape[0]
 
-    def shuffle(self, generator: Optional[torch.Generator] = None):
-        perm = torch.randperm(len(self), device=self.coords.device, generator=generator)
+    def shuffle(self, generator: Optional[torch.Generator] = None, group_chunk: Optional[int] = None):
+        """Random permutation of the sample list (the reference's collate_fn shuffle).  With group_chunk = n_samples
+        every chunk [k*n, (k+1)*n) -- one step's batch -- is additionally ordered by subject: a batch is a set (the
+        step's loss is a mean over it), and a grouped batch lets the backward skip its counting sort and read each
+        subject's rows in place (cinema_affine_trilerp_bwd_sorted)."""
+        m = len(self)
+        perm = torch.randperm(m, device=self.coords.device, generator=generator)
+        if group_chunk:
+            key = (torch.arange(m, device=perm.device) // int(group_chunk)) * self.n_subjects + self.subj[perm].long()
+            perm = perm[torch.argsort(key, stable=True)]
+            del key
         self.coords = self.coords[perm]
         self.voxel = self.voxel[perm]
         self.subj = self.subj[perm]
+        self.group_chunk = int(group_chunk) if group_chunk else 0
 
     @staticmethod
     def synthetic(n_subjects: int, shape, spacing: float, world_bbox, sr_dims: int, n_labels: int, seed: int, device,
@@ -153,10 +164,11 @@ class HotPathTrainer:
         if self.train_mlp and self.world > 1:
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
         want_tf = self.tfs.requires_grad
+        grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
                                     want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
-                                    dlat_out=self.lat_grad)
+                                    dlat_out=self.lat_grad, grouped=grouped)
         if want_tf and self.tf_weight != 0.0:
             self._add_tf_regulariser_grad(subj, n)
         self.latents.grad = self.lat_grad
@@ -185,7 +197,7 @@ class HotPathTrainer:
 
     def epoch(self, n_samples: int, generator: Optional[torch.Generator] = None, max_steps: Optional[int] = None):
         """One pass over the shuffled foreground list in chunks of n_samples (build_atlas.py:65-68)."""
-        self.store.shuffle(generator)
+        self.store.shuffle(generator, group_chunk=n_samples)
         m = len(self.store)
         total = (m + n_samples - 1) // n_samples
         if max_steps is not None:

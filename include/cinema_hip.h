@@ -148,6 +148,16 @@ int cinema_affine_trilerp_bwd(const float *coords, const int32_t *idx, const flo
                               int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
                               float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream);
 
+/* Same, for a batch whose samples are already grouped by subject (idx non-decreasing; the trainer sorts every
+ * step-sized chunk of the epoch's shuffled list once per epoch -- a batch is a set, build_atlas.py:69-88 does not depend
+ * on the order inside it): no counting sort, the per-subject ranges come from a lower_bound inside the first kernel and
+ * the reductions read their rows in place.  The precondition is the caller's; it is not checked. */
+int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                     int32_t embed_per_sample, const float *affine, const float *shadow,
+                                     const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
+                                     int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                                     float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream);
+
 /* -------------------------------------------------------------------------------------
  * K3: ground-truth sampling + loss + dLoss/dOutput (Criterion.forward, utils.py:88-104,
  * and the integer gather `vol[c_nz]` of data_loading/dataset.py:87-89).

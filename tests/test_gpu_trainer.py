@@ -89,8 +89,8 @@ def test_g7_adamw_trajectory_golden():
         assert np.abs(p.detach().cpu().numpy() - g["q_" + n]).max() < 2e-2 * max(move, 1e-12), n
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_trainer_step_matches_oracle(precision):
+@pytest.mark.parametrize("precision,grouped", [("fp32", False), ("bf16", False), ("fp32", True)])
+def test_trainer_step_matches_oracle(precision, grouped):
     """The autograd-free step: gradients it leaves behind == CPU oracle on the same samples (targets gathered from
     the resident volumes: labels bit-exact), and the parameters move as torch.optim.AdamW would move them."""
     from oracle import cinema_oracle as O
@@ -99,7 +99,9 @@ def test_trainer_step_matches_oracle(precision):
     args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
     torch.manual_seed(21)
     store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
-    store.shuffle(torch.Generator(device=DEV).manual_seed(1))
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700 if grouped else None)
+    if grouped:      # every step-sized chunk is sorted by subject -> the sorted K1 backward entry point is taken
+        assert bool((store.subj[:700][1:] >= store.subj[:700][:-1]).all()) and bool((store.subj[700:1400][1:] >= store.subj[700:1400][:-1]).all())
     tr = HotPathTrainer(args, store, DEV)
     with torch.no_grad():
         tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
