@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--loss", default="mse", choices=["mse", "l1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank dry run on a 1-GPU box: every rank uses cuda:0 and the gradient travels over gloo "
+                         "(checks the rank logic; the number it prints is not a result)")
     opt = ap.parse_args()
 
     import torch.distributed as dist
@@ -101,10 +104,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if opt.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if opt.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if opt.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {opt.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -140,7 +148,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if opt.rehearse_on_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = trainer.loss_dict()
@@ -194,7 +202,7 @@ def main():
     res = {
         "metric": "coord samples/sec fwd+bwd (hidden 512)", "value": value, "unit": "coord samples/s", "n_gpus": world,
         "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic" if not opt.rehearse_on_one_gpu else "synthetic (REHEARSAL on one GPU over gloo: not a result)",
         "config": {"workload": "dhcp_neo_mm shape on MI355X: latent 256x3x3x3, hidden 512, 5 hidden layers (mod 1,3,5), "
                                f"out 2+10, {opt.subjects} synthetic subjects of {opt.grid}^3 voxels per GPU, "
                                f"n_samples {n} per GPU per step, {opt.loss} + weighted CE, AdamW step included",
