@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   // byte offset of (sample i of sample tile 0, feature fb) inside a [64 x HP] bf16 tile; tile st adds st*16*HP*2
   const unsigned toff = (i * a.HP + fb) * 2u;
   const unsigned tstep = 16u * a.HP * 2u;
+  const bool keep = a.saved != nullptr;   // NULL: inference, nothing is kept for a backward
 
   FUSED_TRACE(0)
   WRing r;
@@ -280,8 +281,10 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) sv[j] = acc[j >> 2][st][j & 3];
           pack16(sv, sp[st][0], sp[st][1]);
-          *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep)) = sp[st][0];
-          *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
+          if (keep) {
+            *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep)) = sp[st][0];
+            *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
+          }
         }
       }
       feature_vec(bs, a.lb_b[l], fb_l, v);
@@ -312,8 +315,10 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
           for (int j = 0; j < 16; ++j) zv[j] = acc[j >> 2][st][j & 3];
           bf16x8 zlo, zhi;
           pack16(zv, zlo, zhi);
-          *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep)) = zlo;
-          *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep + 16u)) = zhi;
+          if (keep) {
+            *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep)) = zlo;
+            *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep + 16u)) = zhi;
+          }
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             const float sj = (float)(j < 8 ? sp[st][0][j & 7] : sp[st][1][j & 7]);
@@ -343,10 +348,12 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
         bf16x8 ylo, yhi, clo, chi;
         pack16(yv, ylo, yhi);
         pack16(cv, clo, chi);
-        *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep)) = ylo;
-        *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep + 16u)) = yhi;
-        *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep)) = clo;
-        *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep + 16u)) = chi;
+        if (keep) {
+          *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep)) = ylo;
+          *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep + 16u)) = yhi;
+          *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep)) = clo;
+          *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep + 16u)) = chi;
+        }
         lds_char *xr = xs + (16 * st + i_l) * a.xrow;
         *(LDS_AS bf16x8 *)(xr + ((c0 ^ i_l) << 4)) = ylo;
         *(LDS_AS bf16x8 *)(xr + (((c0 + 1) ^ i_l) << 4)) = yhi;

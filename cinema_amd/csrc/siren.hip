@@ -708,7 +708,10 @@ static int forward_impl(const cinema_siren_desc *d, const float *params, const v
 extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *params, const void *packed,
                                     const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
                                     float *out, void *stream) {
-  CINEMA_REQUIRE(d && params && packed && coords_t && lat && saved && out, "cinema_siren_forward: null argument");
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && out, "cinema_siren_forward: null argument");
+  CINEMA_REQUIRE(saved != nullptr || fused_mode(d) == 64,
+                 "cinema_siren_forward: saved == NULL (inference, nothing kept) needs the activation-stationary path "
+                 "(bf16, hidden <= 512); the layer-by-layer kernels pass activations through `saved`");
   CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0, "cinema_siren_forward: need 1 <= N <= Npad, Npad %% 128 == 0 (N=%ld Npad=%ld)",
                  (long)N, (long)Npad);
   CINEMA_REQUIRE(Npad / 128 * ((d->HP + 127) / 128) < (1 << 30), "grid too large");

@@ -139,13 +139,19 @@ class SirenEngine:
         check(self.lib.cinema_siren_pack(C.byref(self.desc), ptr(self.flat), ptr(self.packed), self.stream()),
               "cinema_siren_pack")
 
-    def forward(self, n: int) -> torch.Tensor:
-        """Run the stack on ws.coords_t / ws.lat (already filled for n rows). Returns ws.out."""
+    def can_skip_saved(self) -> bool:
+        """True when a forward may run without keeping activations (the activation-stationary bf16 kernels)."""
+        return self.desc.pk_fs >= 0 and os.environ.get("CINEMA_SIREN_LAYERED") != "1"
+
+    def forward(self, n: int, keep: bool = True) -> torch.Tensor:
+        """Run the stack on ws.coords_t / ws.lat (already filled for n rows). Returns ws.out.
+        keep=False (inference): nothing is saved for a backward where the kernels allow it."""
         ws = self.ws
         npad = round_up(n, ROW_ALIGN)
         self.version += 1
+        saved = ws.saved if (keep or not self.can_skip_saved()) else None
         check(self.lib.cinema_siren_forward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
-                                            ptr(ws.lat), n, npad, ptr(ws.saved), ptr(ws.out), self.stream()),
+                                            ptr(ws.lat), n, npad, ptr(saved), ptr(ws.out), self.stream()),
               "cinema_siren_forward")
         return ws.out
 

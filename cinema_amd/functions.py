@@ -15,6 +15,7 @@ class DecoderState:
         self.engine = eng
         self.k1 = E.TrilerpState()
         self.pack_sig = None
+        self.keep_saved = True      # False for a forward under no_grad: the engine then keeps nothing for a backward
 
 
 def _as_f32(t: torch.Tensor, device) -> torch.Tensor:
@@ -44,7 +45,7 @@ class DecoderFunction(torch.autograd.Function):
         eng.workspace(n)
         _maybe_pack(state, params)
         E.k1_forward(eng, state.k1, coords_c, idx_c, lat_c, cond_c, tfs_c, tf_per_sample, n)
-        out = eng.forward(n)[:n].clone()
+        out = eng.forward(n, keep=state.keep_saved)[:n].clone()     # no_grad / inference: nothing is kept
         ctx.state, ctx.n, ctx.version = state, n, eng.version
         ctx.tf_per_sample = tf_per_sample
         ctx.lat_shape = tuple(lat_c.shape)
@@ -105,7 +106,7 @@ class SirenFunction(torch.autograd.Function):
         ws.coords_t[:n].copy_(coords.detach())
         ws.lat[:npad].zero_()
         ws.lat[:n, :eng.desc.lat].copy_(latent.detach())
-        out = eng.forward(n)[:n].clone()
+        out = eng.forward(n, keep=state.keep_saved)[:n].clone()
         ctx.state, ctx.n, ctx.version = state, n, eng.version
         return out
 

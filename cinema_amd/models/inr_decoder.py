@@ -94,6 +94,7 @@ class INR_Decoder(nn.Module):
         table = self.modulator(latent_vecs)
         if table.dim() != 5:
             raise ValueError("latent_vecs must be (S, C, lx, ly, lz)")
+        st.keep_saved = torch.is_grad_enabled()      # grad mode is off inside Function.forward: read it here
         return DecoderFunction.apply(st, coords, table, condition_vecs, tfs, idcs_df, not tf_table, *st.param_list)
 
     # ------------------------------------------------------------------------------------

@@ -155,4 +155,5 @@ class Siren(nn.Module):
         st = self.hot_state(coords.device)
         if coords.shape[0] == 0:
             return coords.new_zeros((0, self.out_size))
+        st.keep_saved = torch.is_grad_enabled()
         return SirenFunction.apply(st, coords, latent, *st.param_list)

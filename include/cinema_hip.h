@@ -97,7 +97,9 @@ int cinema_siren_pack(const cinema_siren_desc *d /* host */, const float *params
 /* Siren.forward (models/siren.py:59-61) incl. every SineLayer.forward (siren.py:26-36):
  *   out[n, :] = final_linear(cat(x_L, lat)),  x_{l+1} = sin(w z) | sin(w z s + t).
  * coords_t [Npad x 3] fp32 (registered coordinates), lat [Npad x LP] T,
- * saved [n_saved x Npad x HP] T (kept for backward), out [Npad x out_dim] fp32. */
+ * saved [n_saved x Npad x HP] T (kept for backward), out [Npad x out_dim] fp32.
+ * Inference (models/inr_decoder.py:38-48 runs under no_grad): saved may be NULL when the descriptor runs the
+ * activation-stationary kernels (bf16, hidden <= 512; pk_fs >= 0) -- nothing is written but `out`. */
 int cinema_siren_forward(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
                          const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
                          float *out, void *stream);

@@ -289,3 +289,38 @@ def test_state_dict_roundtrip_and_deepcopy():
     dec3.load_state_dict(sd)
     y2 = dec3(x[0], x[1], torch.zeros(50, 0, device=dev()), None, idcs_df=idx)
     assert torch.equal(y0, y2)
+
+
+def test_inference_forward_keeps_nothing_and_matches():
+    """no_grad forward (cinema_siren_forward with saved == NULL on the activation-stationary path) is bit-identical to
+    the training forward, leaves the saved buffer untouched, and the layer-by-layer (fp32) path refuses saved == NULL."""
+    import ctypes as C
+    from cinema_amd import _lib
+    from cinema_amd._lib import ptr
+    c = CFGS["cfgD"]
+    g = load_golden("g5_decoder_cfgD.npz")
+    dec, _ = _load_decoder(g, c["latent_dim"], c["hidden"], c["layers"], c["mod"], c["out_dim"], c["cond"], "bf16")
+    lat = T(g["lat"]).to(dev())
+    coords, idx = T(g["coords"]).to(dev()), T(g["idx"]).to(dev())
+    cond = T(g["cond"]).to(dev())
+    tfs = T(g["tft"]).to(dev())[idx.long()]
+    y_train = dec(coords, lat.clone().requires_grad_(True), cond, tfs, idcs_df=idx).detach().clone()
+    eng = dec.sr_net.hot_state(dev()).engine
+    assert eng.can_skip_saved()
+    eng.ws.saved.fill_(7.0)
+    with torch.no_grad():
+        y_inf = dec(coords, lat, cond, tfs, idcs_df=idx)
+    assert torch.equal(y_inf, y_train)
+    assert bool((eng.ws.saved == 7.0).all()), "inference forward wrote saved activations"
+    assert rel_err(y_inf.cpu().numpy(), g["out"]) < TOL["bf16"]
+
+    dec32, _ = _load_decoder(g, c["latent_dim"], c["hidden"], c["layers"], c["mod"], c["out_dim"], c["cond"], "fp32")
+    with torch.no_grad():
+        y32 = dec32(coords, lat, cond, tfs, idcs_df=idx)          # falls back to keeping the activations
+    assert rel_err(y32.cpu().numpy(), g["out"]) < TOL["fp32"]
+    e32 = dec32.sr_net.hot_state(dev()).engine
+    assert not e32.can_skip_saved()
+    n = coords.shape[0]
+    rc = e32.lib.cinema_siren_forward(C.byref(e32.desc), ptr(e32.flat), ptr(e32.packed), ptr(e32.ws.coords_t), ptr(e32.ws.lat),
+                                      n, (n + 127) // 128 * 128, None, ptr(e32.ws.out), e32.stream())
+    assert rc != 0 and b"saved" in e32.lib.cinema_last_error()

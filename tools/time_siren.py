@@ -40,3 +40,4 @@ timeit("backward: dlat", lambda: eng.backward(N, ws.dout, weight_grads=True, pha
 timeit("backward: dW grouped", lambda: eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW))
 timeit("backward: all", lambda: eng.backward(N, ws.dout, weight_grads=True))
 timeit("backward: chain, frozen weights", lambda: eng.backward(N, ws.dout, weight_grads=False, phases=_lib.BWD_PHASE_CHAIN))
+timeit("forward stack, inference (nothing kept)", lambda: eng.forward(N, keep=False))
