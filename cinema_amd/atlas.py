@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel as par
-from .utils import generate_combinations, generate_world_grid, normalize_condition
+from .utils import generate_combinations, generate_world_grid, normalize_condition, save_atlas
 
 
 def gaussian_sigma(args: dict, condition_key: str) -> float:
@@ -69,10 +69,12 @@ def atlas_jobs(args: dict) -> Tuple[List[float], List[List[float]], List[Tuple[i
 
 
 def generate_atlas(decoder, args: dict, latents: torch.Tensor, scan_age_values: torch.Tensor, n_max: int = 100,
-                   process_group=None, device=None):
-    """build_atlas.py:159-188 without the NIfTI writer.  Returns (atlas, affine, temp_steps, condition_vectors) with
-    atlas [x, y, z, modalities, conditions, t] on the CPU when run on one rank; with a process group every rank returns
-    {(ti, ci): volume} for the jobs it owns instead of the stacked tensor (volumes are written where they are made)."""
+                   process_group=None, device=None, epoch: Optional[int] = None):
+    """build_atlas.py:159-188.  Returns (atlas, affine, temp_steps, condition_vectors) with atlas
+    [x, y, z, modalities, conditions, t] on the CPU when run on one rank; with a process group every rank returns
+    {(ti, ci): volume} for the jobs it owns instead of the stacked tensor.  With `epoch` given the atlas is also written
+    like utils.save_atlas (utils.py:253-271) does -- under a process group the volumes are first brought to rank 0
+    (parallel.collect_jobs), which writes the files."""
     device = device or args["device"]
     rank, world = par.world_info(process_group)
     decoder.eval()
@@ -94,8 +96,19 @@ def generate_atlas(decoder, args: dict, latents: torch.Tensor, scan_age_values: 
                 seg[seg == 4] = 0                                       # build_atlas.py:178-180
                 values_p[:, :, :, -1] = seg
                 volumes[(ti, ci)] = values_p.detach().cpu()
+    n_c = len(condition_vectors)
     if world > 1:
+        if epoch is not None:
+            flat = par.collect_jobs({ti * n_c + ci: v for (ti, ci), v in volumes.items()}, len(jobs), process_group)
+            if rank == 0:
+                save_atlas(args, _stack_atlas(flat, len(temp_steps), n_c), affine, temp_steps, condition_vectors, epoch)
         return volumes, affine, temp_steps, condition_vectors
-    atlas = torch.stack([torch.stack([volumes[(ti, ci)] for ci in range(len(condition_vectors))], dim=-1)
-                         for ti in range(len(temp_steps))], dim=-1)
+    atlas = _stack_atlas([volumes[j] for j in jobs], len(temp_steps), n_c)
+    if epoch is not None:
+        save_atlas(args, atlas, affine, temp_steps, condition_vectors, epoch)
     return atlas, affine, temp_steps, condition_vectors
+
+
+def _stack_atlas(flat: List[torch.Tensor], n_t: int, n_c: int) -> torch.Tensor:
+    """[t-major list of (x, y, z, m)] -> [x, y, z, m, conditions, t] (build_atlas.py:185-186)."""
+    return torch.stack([torch.stack([flat[ti * n_c + ci] for ci in range(n_c)], dim=-1) for ti in range(n_t)], dim=-1)

@@ -8,7 +8,7 @@ gloo in the CPU tests).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -92,3 +92,37 @@ def gather_rows(local: torch.Tensor, process_group=None) -> torch.Tensor:
 def shard_jobs(n_jobs: int, rank: int, world: int) -> List[int]:
     """Round-robin split of independent jobs ((time point x condition) atlas volumes) over ranks."""
     return list(range(rank, n_jobs, world))
+
+
+def collect_jobs(mine: Dict[int, torch.Tensor], n_jobs: int, process_group=None, device=None, dst: int = 0):
+    """Bring the results of round-robin jobs (`shard_jobs`) to rank `dst`, in job order: the atlas volumes that
+    utils.save_atlas stacks over time points (the reference holds the whole atlas on one host, build_atlas.py:181-187).
+    Point-to-point, one volume in flight: rank `dst` receives job after job from its owner while every other rank sends
+    its own jobs in the same order, so the exchange cannot deadlock.  Tensors travel through `device` (the GPU under
+    RCCL, the CPU under gloo).  Returns the list of CPU tensors on `dst`, None elsewhere."""
+    rank, world = world_info(process_group)
+    if world == 1:
+        return [mine[j] for j in range(n_jobs)]
+    if device is None:
+        device = "cpu" if dist.get_backend(process_group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    out = [] if rank == dst else None
+    for j in range(n_jobs):
+        owner = j % world
+        if rank == dst:
+            if owner == dst:
+                out.append(mine[j])
+                continue
+            meta = torch.zeros(8, dtype=torch.int64, device=device)
+            dist.recv(meta, src=owner, group=process_group)
+            nd = int(meta[0])
+            buf = torch.empty([int(x) for x in meta[1:1 + nd]], dtype=torch.float32, device=device)
+            dist.recv(buf, src=owner, group=process_group)
+            out.append(buf.cpu())
+        elif owner == rank:
+            v = mine[j].to(device=device, dtype=torch.float32).contiguous()
+            meta = torch.zeros(8, dtype=torch.int64, device=device)
+            meta[0] = v.dim()
+            meta[1:1 + v.dim()] = torch.tensor(v.shape, dtype=torch.int64)
+            dist.send(meta, dst=dst, group=process_group)
+            dist.send(v, dst=dst, group=process_group)
+    return out

@@ -33,12 +33,14 @@ class SubjectStore:
     (dataset.py:36-47) so that a step is a contiguous slice."""
 
     def __init__(self, intens: torch.Tensor, labels: torch.Tensor, voxels_per_subject: int, coords: torch.Tensor,
-                 voxel: torch.Tensor, subj: torch.Tensor, conditions: Optional[torch.Tensor] = None):
+                 voxel: torch.Tensor, subj: torch.Tensor, conditions: Optional[torch.Tensor] = None,
+                 n_subjects: Optional[int] = None):
+        # voxels_per_subject = 0: compact tables (cinema_amd/dataset.py) -- `voxel` is then a global row of intens/labels
         self.intens, self.labels, self.V = intens, labels, int(voxels_per_subject)
         self.coords, self.voxel, self.subj = coords, voxel, subj
         self.conditions = conditions          # (S, cond_dims) normalised, or None
         self.group_chunk = 0                  # > 0: every chunk of this many samples is sorted by subject
-        self.n_subjects = labels.numel() // self.V
+        self.n_subjects = int(n_subjects) if n_subjects is not None else labels.numel() // self.V
 
     def __len__(self):
         return self.coords.shape[0]

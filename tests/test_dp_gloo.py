@@ -172,3 +172,21 @@ def test_mean_latent_single_process_matches_golden():
         assert rel_err(m.numpy(), g[f"ml{i}_out"]) < 1e-6
     with pytest.raises(AssertionError):
         atlas.mean_latent(args, lat, cv[:3], "scan_age", 0.0)
+
+
+def _collect_worker(rank):
+    from cinema_amd import parallel as par
+    n_jobs = 5
+    vol = lambda j: torch.full((2, 3, 4, 2), float(j)) + torch.arange(2.0)
+    mine = {j: vol(j) for j in par.shard_jobs(n_jobs, rank, WORLD)}
+    got = par.collect_jobs(mine, n_jobs)
+    if rank == 0:
+        assert len(got) == n_jobs
+        for j in range(n_jobs):
+            assert torch.equal(got[j], vol(j)), j
+    else:
+        assert got is None
+
+
+def test_collect_jobs_brings_round_robin_volumes_to_rank_0_in_order():
+    _run(_collect_worker)

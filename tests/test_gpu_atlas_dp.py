@@ -63,6 +63,30 @@ def test_generate_atlas_matches_oracle():
             assert np.abs(got[..., 3:].numpy() - ref[..., 3:].numpy()).max() < 2e-4
 
 
+def test_generate_atlas_writes_the_reference_file_set(tmp_path):
+    """epoch given -> utils.save_atlas layout (utils.py:253-271): one 4-d .nii.gz (x, y, z, t) per modality / certainty
+    map and condition, holding exactly the returned atlas, affine diag(spacing, 1)."""
+    from cinema_amd import atlas, nifti
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import normalize_condition
+    args = atlas_args("bf16")
+    args["dataset"].update(modalities=["T2w", "T1w", "Seg"], label_names=["BG", "a", "b", "c", "d"])
+    args.update(save_certainty_maps=True, output_dir=str(tmp_path))
+    torch.manual_seed(3)
+    dec = INR_Decoder(args, DEV).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(6, 16, 3, 3, 3, generator=g) * 0.3
+    cv = normalize_condition(args, "scan_age", torch.rand(6, generator=g) * 9 + 37)
+    vol, affine, tsteps, conds = atlas.generate_atlas(dec, args, lat.to(DEV), cv.to(DEV), n_max=5, epoch=3)
+    names = ["T2w", "T1w", "Seg"] + [f"CertaintyMaps/{n}" for n in args["dataset"]["label_names"]]
+    for c in range(len(conds)):
+        for i, nme in enumerate(names):
+            img = nifti.load(os.path.join(str(tmp_path), f"{nme}_ga=38.0-43.5_cond={c}_ep=3.nii.gz"))
+            assert img.shape == (12, 12, 12, 2) and img.get_data_dtype() == np.float32
+            assert np.array_equal(img.get_fdata(), vol[..., i, c, :].numpy().astype(np.float64), equal_nan=True)
+            assert np.array_equal(np.diag(img.affine), [5.0, 5.0, 5.0, 1.0])
+
+
 # ------------------------------------------------------------------------------------------------
 def _free_port():
     with socket.socket() as s:
