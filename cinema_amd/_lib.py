@@ -33,7 +33,7 @@ class SirenDesc(C.Structure):
         ("pk_wf", C.c_int64), ("pk_total", C.c_int64),
         ("sv_y", _i32L), ("sv_c", _i32L), ("sv_z", _i32L), ("sv_s", _i32L),
         ("gb_z", _i32L), ("gb_s", _i32L), ("gb_t", _i32L),
-        ("pk_fs", C.c_int64), ("pk_bs", C.c_int64), ("pk_side", C.c_int64), ("fs_steps", C.c_int32), ("bs_steps", C.c_int32),
+        ("pk_fs", C.c_int64), ("pk_bs", C.c_int64), ("pk_side", C.c_int64), ("fs_steps", C.c_int32), ("bs_steps", C.c_int32), ("gb_extra_bytes", C.c_int64),
     ]
 
 

@@ -377,6 +377,162 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------
+// bf16, wide stacks: the same grouped weight-gradient GEMMs on 256 x 256 output tiles.
+// With 128 x 128 tiles a 512 x 512 problem re-reads both operand slabs four times through L2 -> CU (1.3 GB per step at
+// cfg-D, the chip-wide L2 rate is ~17 TB/s) and every split adds its tile with float atomics (~1.3 TB/s chip-wide).
+// Here: 8 waves (2 x 4), wave tile 128 x 64 (acc = 128 registers), operands [n][feature] staged global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass; the XOR swizzle of the LDS image goes on
+// the per-lane SOURCE address, the destination is lane-linear), two 64-sample buffers, fragments by
+// ds_read_b64_tr_b16.  Splits write plain fp32 slabs; k_dw256_reduce sums them (deterministic, no atomics).
+// ----------------------------------------------------------------------------------------
+#define DW256_THREADS 512
+#define DW256_BN 64                               // samples per staged tile
+#define DW256_ROWB 512                            // LDS row: 256 bf16 columns
+#define DW256_TILE (DW256_BN * DW256_ROWB)        // 32 KB per operand tile
+#define DW256_SMEM (4 * DW256_TILE)               // 2 operands x 2 buffers
+#define DW256_MAX_SPLIT 8
+
+struct Dw256Args { DwArgs g; float *slab; };
+typedef __attribute__((address_space(1))) const void gmem_cvoid;
+
+__device__ __forceinline__ int dw256_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int dw256_off(int row, int colbyte) {
+  return row * DW256_ROWB + ((((colbyte >> 4) ^ (dw256_key(row) << 1)) << 4) | (colbyte & 15));
+}
+// fragment of 16 columns x 32 rows (k = sample): lanes 16g..16g+15 fetch rows nbase+8g+{0..7}
+__device__ __forceinline__ bf16x8 dw256_frag(const lds_char *tile, int nbase, int colbase, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r0 = nbase + 8 * g + q;
+  typedef LDS_AS s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tile + dw256_off(r0, (colbase + 4 * p) * 2)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tile + dw256_off(r0 + 4, (colbase + 4 * p) * 2)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// rows n0..n0+63 of X [n][ld], columns col0..col0+255 -> LDS image [64][512 B]; one wave-instruction fills two rows
+__device__ __forceinline__ void dw256_stage(const bf16_t *X, int ld, int col0, long n0, lds_char *dst, int wave, int lane) {
+  const int pos = lane & 31, rsub = lane >> 5;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = 16 * rr + 2 * wave + rsub;
+    int col = col0 + ((pos ^ (dw256_key(row) << 1)) << 3);
+    if (col + 8 > ld) col = 0;
+    __builtin_amdgcn_global_load_lds((gmem_cvoid *)(X + (n0 + row) * ld + col), dst + (16 * rr + 2 * wave) * DW256_ROWB, 16, 0, 0);
+  }
+}
+
+// One staged tile: wait for it, start the DMA of the next tile into the other buffer, multiply.  `cur` / `nxt` are
+// __restrict__ on purpose: the scoped-noalias metadata this leaves on the LDS reads and on the LDS-DMA writes is what
+// lets hipcc's waitcnt pass see that the fragment reads do not depend on the DMA just issued (without it every first
+// ds_read of a tile waits vmcnt(0), i.e. for the NEXT tile, and the pipeline is serial).
+template <int NHT>
+__device__ __forceinline__ void dw256_mma(f32x4 (&acc)[8][4], const lds_char *__restrict__ sP, const lds_char *__restrict__ sQ,
+                                          int wh, int wk, int lane) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bf16x8 b[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) b[kt] = dw256_frag(sQ, kk * 32, wk * 64 + kt * 16, lane);
+#pragma unroll
+    for (int ht = 0; ht < NHT; ++ht) {
+      const bf16x8 af = dw256_frag(sP, kk * 32, wh * 128 + ht * 16, lane);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[kt], acc[ht][kt], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void dw256_iter(f32x4 (&acc)[8][4], lds_char *__restrict__ cur, lds_char *__restrict__ nxt,
+                                           const bf16_t *P, int ldp, int h0, const bf16_t *Q, int ldq, int c0, bool more,
+                                           long n1, int nht, int wave, int wh, int wk, int lane) {
+  // tile has landed (own DMAs: vmcnt, everyone's: barrier) and every wave is done with the other buffer
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (more) {
+    dw256_stage(P, ldp, h0, n1, nxt, wave, lane);
+    dw256_stage(Q, ldq, c0, n1, nxt + DW256_TILE, wave, lane);
+  }
+  // rows beyond M multiply clamped (valid) columns and are masked at the store: only the one-subtile case of the
+  // final_linear rows (out_dim <= 16) is worth a variant of its own
+  if (nht >= 2) dw256_mma<8>(acc, cur, cur + DW256_TILE, wh, wk, lane);
+  else if (nht == 1) dw256_mma<1>(acc, cur, cur + DW256_TILE, wh, wk, lane);
+}
+
+__global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char *base = (lds_char *)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wh = wave >> 2, wk = wave & 3;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+  while (pi + 1 < a.g.nprob && lid >= a.g.tile_start[pi + 1] * a.g.splitk) ++pi;
+  const DwProb pr = a.g.p[pi];
+  const int ntp = a.g.tile_start[pi + 1] - a.g.tile_start[pi];
+  const int rel = lid - a.g.tile_start[pi] * a.g.splitk;
+  const int split = rel / ntp, t = rel - split * ntp;
+  const int h0 = (t / pr.tk) * 256, c0 = (t % pr.tk) * 256;
+  const int ntile = a.g.Npad / DW256_BN;
+  const long nbeg = (long)((long)ntile * split / a.g.splitk) * DW256_BN;
+  const int nt = (int)((long)ntile * (split + 1) / a.g.splitk) - (int)((long)ntile * split / a.g.splitk);
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
+  const int rows_left = pr.M - h0 - wh * 128, cols_left = pr.K - c0 - wk * 64;
+  const int nht = __builtin_amdgcn_readfirstlane(
+      (rows_left <= 0 || cols_left <= 0) ? 0 : (rows_left >= 128 ? 8 : (rows_left + 15) >> 4));
+  const bf16_t *P = (const bf16_t *)pr.P, *Q = (const bf16_t *)pr.Q;
+  if (nt > 0) {
+    dw256_stage(P, pr.ldp, h0, nbeg, base, wave, lane);
+    dw256_stage(Q, pr.ldq, c0, nbeg, base + DW256_TILE, wave, lane);
+  }
+  for (int it = 0; it < nt; it += 2) {
+    dw256_iter(acc, base, base + 2 * DW256_TILE, P, pr.ldp, h0, Q, pr.ldq, c0, it + 1 < nt, nbeg + (long)(it + 1) * DW256_BN,
+               nht, wave, wh, wk, lane);
+    if (it + 1 >= nt) break;
+    dw256_iter(acc, base + 2 * DW256_TILE, base, P, pr.ldp, h0, Q, pr.ldq, c0, it + 2 < nt, nbeg + (long)(it + 2) * DW256_BN,
+               nht, wave, wh, wk, lane);
+  }
+  float *slab = a.slab + ((size_t)(a.g.tile_start[pi] + t) * a.g.splitk + split) * (256 * 256);
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int ht = 0; ht < 8; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int col = wk * 64 + kt * 16 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wh * 128 + ht * 16 + 4 * g + r;
+        if (h0 + row < pr.M && c0 + col < pr.K) slab[row * 256 + col] = acc[ht][kt][r];
+      }
+    }
+}
+
+// out[h][k] = sum over the splits of one tile; block = 8 rows of one tile, thread = 8 columns
+__global__ __launch_bounds__(256) void k_dw256_reduce(Dw256Args a) {
+  const int tg = blockIdx.x >> 5, rb = blockIdx.x & 31;
+  int pi = 0;
+  while (pi + 1 < a.g.nprob && tg >= a.g.tile_start[pi + 1]) ++pi;
+  const DwProb pr = a.g.p[pi];
+  const int t = tg - a.g.tile_start[pi];
+  const int h0 = (t / pr.tk) * 256, c0 = (t % pr.tk) * 256;
+  const int row = rb * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 8;
+  if (h0 + row >= pr.M || c0 + col >= pr.K) return;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  const float *src = a.slab + (size_t)tg * a.g.splitk * (256 * 256) + row * 256 + col;
+  for (int sp = 0; sp < a.g.splitk; ++sp) {
+    s0 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256));
+    s1 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256) + 4);
+  }
+  float *out = pr.out + (size_t)(h0 + row) * pr.ldo + c0 + col;
+  const int nv = pr.K - c0 - col;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < nv) out[j] = j < 4 ? s0[j & 3] : s1[j & 3];
+}
+
+// ----------------------------------------------------------------------------------------
 // final linear (siren.py:61):  out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]
 // one wave per 16 samples, weights (padded to 16 rows) staged once per workgroup in LDS
 // ----------------------------------------------------------------------------------------
@@ -567,6 +723,17 @@ extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
   d->pk_total = pk;
   d->n_saved = sv;
   d->n_gbuf = gb + 1;   // last slot: dOut as [Npad x 16] T for the final_linear weight gradient
+  // bf16 stacks with hidden >= 256: the weight-gradient GEMMs run on 256 x 256 tiles whose sample splits leave fp32
+  // partial tiles in a slab region the caller appends to gbuf (k_dw256)
+  d->gb_extra_bytes = 0;
+  if (d->precision == CINEMA_PREC_BF16 && H >= 256) {
+    auto t256 = [](long M, long K) { return ((M + 255) / 256) * ((K + 255) / 256); };
+    long tiles = t256(d->out_dim, H) + t256(d->out_dim, L);
+    for (int i = 1; i < d->n_layers; ++i) tiles += t256(H, H);
+    for (int i = 0; i < d->n_layers; ++i)
+      if ((d->modulated_mask >> i) & 1u) tiles += 2 * t256(H, L);
+    d->gb_extra_bytes = tiles * 8 /* DW256_MAX_SPLIT */ * 256 * 256 * 4 + 256;
+  }
   return 0;
 }
 
@@ -858,6 +1025,46 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     a.tile_start[np] = tiles;
     a.nprob = np;
     a.Npad = (int)Npad;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (d->gb_extra_bytes > 0 && Npad >= 4096) {
+        // 256 x 256 tiles, one workgroup per CU; partial tiles go to the slab region behind the gbuf tensors
+        Dw256Args b = {};
+        int t256 = 0;
+        for (int q = 0; q < np; ++q) {
+          b.g.p[q] = a.p[q];
+          b.g.p[q].tk = (a.p[q].K + 255) / 256;
+          b.g.tile_start[q] = t256;
+          t256 += ((a.p[q].M + 255) / 256) * b.g.p[q].tk;
+        }
+        b.g.tile_start[np] = t256;
+        b.g.nprob = np;
+        b.g.Npad = (int)Npad;
+        static int ncu = 0;
+        if (!ncu) {
+          int dev = 0;
+          CINEMA_CHECK_HIP(hipGetDevice(&dev));
+          CINEMA_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        int sk = std::max(1, std::min(DW256_MAX_SPLIT, ncu / std::max(t256, 1)));
+        sk = std::min(sk, std::max(1, (int)(Npad / DW256_BN) / 4));
+        b.g.splitk = sk;
+        CINEMA_REQUIRE((int64_t)t256 * DW256_MAX_SPLIT * 256 * 256 * 4 + 256 <= d->gb_extra_bytes,
+                       "cinema_siren_backward: gb_extra_bytes of the descriptor is smaller than the plan's");
+        const size_t gb_bytes = ((size_t)d->n_gbuf * Npad * HP * sizeof(T) + 255) / 256 * 256;
+        b.slab = (float *)((char *)gbuf + gb_bytes);
+        static bool attr256 = false;
+        if (!attr256) {
+          CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_dw256, hipFuncAttributeMaxDynamicSharedMemorySize, DW256_SMEM));
+          attr256 = true;
+        }
+        hipLaunchKernelGGL(k_dw256, dim3(t256 * sk), dim3(DW256_THREADS), DW256_SMEM, s, b);
+        CINEMA_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_dw256_reduce, dim3(t256 * 32), dim3(256), 0, s, b);
+        CINEMA_CHECK_HIP(hipGetLastError());
+        (void)N;
+        return 0;
+      }
+    }
     const int ntile = (int)(Npad / Engine<T>::BN);
     int splitk = std::max(1, 512 / std::max(tiles, 1));
     splitk = std::min(splitk, std::max(1, ntile / 4));

@@ -87,7 +87,9 @@ class Workspace:
     def ensure_backward(self):
         if self.gbuf is None:
             d, n = self._d, self.npad_cap
-            self.gbuf = torch.empty(d.n_gbuf, n, d.HP, device=self._device, dtype=self._dt)
+            esize = 2 if self._dt == torch.bfloat16 else 4
+            nbytes = round_up(d.n_gbuf * n * d.HP * esize, 256) + int(d.gb_extra_bytes)
+            self.gbuf = torch.empty(nbytes, device=self._device, dtype=torch.uint8)
             self.dlat = torch.empty(n, d.LP, device=self._device, dtype=torch.float32)
             self.dcoords = torch.empty(n, self._in_dim, device=self._device, dtype=torch.float32)
             self.dout = torch.zeros(n, d.out_dim, device=self._device, dtype=torch.float32)

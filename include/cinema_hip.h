@@ -84,6 +84,9 @@ typedef struct cinema_siren_desc {
    * elements into the packed copy, k32 steps per 64-feature slab); -1 / 0 when that path does not apply */
   int64_t pk_fs, pk_bs, pk_side;   /* pk_side: fp32 block of biases + first-layer weights in the kernel's LDS layout */
   int32_t fs_steps, bs_steps;
+  /* bytes of scratch the caller appends behind the n_gbuf tensors of `gbuf` (fp32 partial tiles of the split
+   * weight-gradient reductions; 0 when that path does not apply) */
+  int64_t gb_extra_bytes;
 } cinema_siren_desc;
 
 int cinema_siren_plan(cinema_siren_desc *d /* host */);
@@ -105,7 +108,8 @@ int cinema_siren_forward(const cinema_siren_desc *d /* host */, const float *par
                          float *out, void *stream);
 
 /* Backward of the above (what autograd does for siren.py:26-36,59-61).
- * dout [Npad x out_dim] fp32 (rows >= N must be zero), gbuf [n_gbuf x Npad x HP] T scratch,
+ * dout [Npad x out_dim] fp32 (rows >= N must be zero), gbuf [n_gbuf x Npad x HP] T scratch followed (at the next
+ * multiple of 256 bytes) by gb_extra_bytes more bytes,
  * grad_params [n_params] fp32 (zeroed by this call, then accumulated with atomics),
  * dlat [Npad x LP] fp32 (overwritten), dcoords [Npad x 3] fp32 (overwritten). */
 int cinema_siren_backward(const cinema_siren_desc *d /* host */, const float *params, const void *packed,

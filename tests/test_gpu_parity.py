@@ -218,6 +218,16 @@ def test_oracle_parity_dhcp_shape_tf_table(precision):
     assert not bad, f"{bad}\nall: {errs}"
 
 
+def test_oracle_parity_wide_ragged_256_tiles():
+    """bf16, hidden 320 (HP = 320: a 256-row tile and a 64-row remainder), latent 64 + 1 condition (LP = 128, K = 65),
+    N = 5000 >= 4096: the 256 x 256 weight-gradient tiles with their row / column masks and the slab reduction
+    (hidden > 256 and <= 512 also takes the activation-stationary chains)."""
+    errs = _oracle_case(N=5000, S=9, latent_dim=[64, 2, 2, 2], hidden=320, layers=3, mod=[1, 2], out_dim=[1, 6], cond=1,
+                        seed=23, precision="bf16", tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_oracle_parity_large_batch_grouping_path():
     """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
     errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,
