@@ -191,7 +191,7 @@ def main():
         peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ms_dw = time_phase(_lib.BWD_PHASE_DW)
         macs = n * (5 * d.hidden * d.hidden + 3 * 2 * d.hidden * d.lat)           # dW of 5 linear + 3 linear_lats
-        others.append({"kernel": "k_dw_grouped (all weight-gradient GEMMs, one launch)", "bound": "mfma",
+        others.append({"kernel": "k_dw256 + k_dw256_reduce (all weight-gradient GEMMs: 256x256 tiles, split partials, reduce)", "bound": "mfma",
                        "achieved": 2.0 * macs / (ms_dw * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                        "frac": 2.0 * macs / (ms_dw * 1e-3) / 1e12 / peak, "avg_launch_ms": ms_dw})
 

@@ -386,10 +386,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
 // ds_read_b64_tr_b16.  Splits write plain fp32 slabs; k_dw256_reduce sums them (deterministic, no atomics).
 // ----------------------------------------------------------------------------------------
 #define DW256_THREADS 512
-#define DW256_BN 64                               // samples per staged tile
+#define DW256_BN 32                               // samples per staged tile
 #define DW256_ROWB 512                            // LDS row: 256 bf16 columns
-#define DW256_TILE (DW256_BN * DW256_ROWB)        // 32 KB per operand tile
-#define DW256_SMEM (4 * DW256_TILE)               // 2 operands x 2 buffers
+#define DW256_TILE (DW256_BN * DW256_ROWB)        // 16 KB per operand tile
+#define DW256_NBUF 4                              // tiles k+1..k+3 are in flight while tile k is multiplied
+#define DW256_SMEM (DW256_NBUF * 2 * DW256_TILE)  // 128 KB
 #define DW256_MAX_SPLIT 8
 
 struct Dw256Args { DwArgs g; float *slab; };
@@ -399,63 +400,48 @@ __device__ __forceinline__ int dw256_key(int row) { return (row & 3) | (((row >>
 __device__ __forceinline__ int dw256_off(int row, int colbyte) {
   return row * DW256_ROWB + ((((colbyte >> 4) ^ (dw256_key(row) << 1)) << 4) | (colbyte & 15));
 }
-// fragment of 16 columns x 32 rows (k = sample): lanes 16g..16g+15 fetch rows nbase+8g+{0..7}
-__device__ __forceinline__ bf16x8 dw256_frag(const lds_char *tile, int nbase, int colbase, int lane) {
+// fragment of 16 columns x 32 rows (k = sample): lanes 16g..16g+15 fetch rows 8g+{0..7}
+__device__ __forceinline__ bf16x8 dw256_frag(const lds_char *tile, int colbase, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int r0 = nbase + 8 * g + q;
+  const int r0 = 8 * g + q;
   typedef LDS_AS s16x4 lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tile + dw256_off(r0, (colbase + 4 * p) * 2)));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tile + dw256_off(r0 + 4, (colbase + 4 * p) * 2)));
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
-// rows n0..n0+63 of X [n][ld], columns col0..col0+255 -> LDS image [64][512 B]; one wave-instruction fills two rows
+// LDS-DMA issued from an asm statement: hipcc then knows nothing of it.  Through the builtin its waitcnt pass must
+// assume that every later LDS read depends on the DMA and puts vmcnt(0) in front of the first fragment read of each
+// tile, which leaves one tile in flight instead of three.  The price: completion is counted by hand (below).
+__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// rows n0..n0+31 of X [n][ld], columns col0..col0+255 -> LDS image [32][512 B]; one wave-instruction fills two rows
+// (destination = wave-uniform base + lane * 16: the XOR swizzle of the image is applied to the per-lane SOURCE address)
 __device__ __forceinline__ void dw256_stage(const bf16_t *X, int ld, int col0, long n0, lds_char *dst, int wave, int lane) {
   const int pos = lane & 31, rsub = lane >> 5;
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
+  for (int rr = 0; rr < 2; ++rr) {
     const int row = 16 * rr + 2 * wave + rsub;
     int col = col0 + ((pos ^ (dw256_key(row) << 1)) << 3);
     if (col + 8 > ld) col = 0;
-    __builtin_amdgcn_global_load_lds((gmem_cvoid *)(X + (n0 + row) * ld + col), dst + (16 * rr + 2 * wave) * DW256_ROWB, 16, 0, 0);
+    glds16_asm(X + (n0 + row) * ld + col, (unsigned)(__SIZE_TYPE__)(dst + (16 * rr + 2 * wave) * DW256_ROWB));
   }
 }
 
-// One staged tile: wait for it, start the DMA of the next tile into the other buffer, multiply.  `cur` / `nxt` are
-// __restrict__ on purpose: the scoped-noalias metadata this leaves on the LDS reads and on the LDS-DMA writes is what
-// lets hipcc's waitcnt pass see that the fragment reads do not depend on the DMA just issued (without it every first
-// ds_read of a tile waits vmcnt(0), i.e. for the NEXT tile, and the pipeline is serial).
 template <int NHT>
-__device__ __forceinline__ void dw256_mma(f32x4 (&acc)[8][4], const lds_char *__restrict__ sP, const lds_char *__restrict__ sQ,
-                                          int wh, int wk, int lane) {
+__device__ __forceinline__ void dw256_mma(f32x4 (&acc)[8][4], const lds_char *sP, const lds_char *sQ, int wh, int wk, int lane) {
+  bf16x8 b[4];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    bf16x8 b[4];
+  for (int kt = 0; kt < 4; ++kt) b[kt] = dw256_frag(sQ, wk * 64 + kt * 16, lane);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) b[kt] = dw256_frag(sQ, kk * 32, wk * 64 + kt * 16, lane);
+  for (int ht = 0; ht < NHT; ++ht) {
+    const bf16x8 af = dw256_frag(sP, wh * 128 + ht * 16, lane);
 #pragma unroll
-    for (int ht = 0; ht < NHT; ++ht) {
-      const bf16x8 af = dw256_frag(sP, kk * 32, wh * 128 + ht * 16, lane);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[kt], acc[ht][kt], 0, 0, 0);
-    }
+    for (int kt = 0; kt < 4; ++kt) acc[ht][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[kt], acc[ht][kt], 0, 0, 0);
   }
-}
-
-__device__ __forceinline__ void dw256_iter(f32x4 (&acc)[8][4], lds_char *__restrict__ cur, lds_char *__restrict__ nxt,
-                                           const bf16_t *P, int ldp, int h0, const bf16_t *Q, int ldq, int c0, bool more,
-                                           long n1, int nht, int wave, int wh, int wk, int lane) {
-  // tile has landed (own DMAs: vmcnt, everyone's: barrier) and every wave is done with the other buffer
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (more) {
-    dw256_stage(P, ldp, h0, n1, nxt, wave, lane);
-    dw256_stage(Q, ldq, c0, n1, nxt + DW256_TILE, wave, lane);
-  }
-  // rows beyond M multiply clamped (valid) columns and are masked at the store: only the one-subtile case of the
-  // final_linear rows (out_dim <= 16) is worth a variant of its own
-  if (nht >= 2) dw256_mma<8>(acc, cur, cur + DW256_TILE, wh, wk, lane);
-  else if (nht == 1) dw256_mma<1>(acc, cur, cur + DW256_TILE, wh, wk, lane);
 }
 
 __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
@@ -472,28 +458,51 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
   const int split = rel / ntp, t = rel - split * ntp;
   const int h0 = (t / pr.tk) * 256, c0 = (t % pr.tk) * 256;
   const int ntile = a.g.Npad / DW256_BN;
-  const long nbeg = (long)((long)ntile * split / a.g.splitk) * DW256_BN;
-  const int nt = (int)((long)ntile * (split + 1) / a.g.splitk) - (int)((long)ntile * split / a.g.splitk);
+  const int tbeg = (int)((long)ntile * split / a.g.splitk), tend = (int)((long)ntile * (split + 1) / a.g.splitk);
   f32x4 acc[8][4];
 #pragma unroll
   for (int x = 0; x < 8; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
   const int rows_left = pr.M - h0 - wh * 128, cols_left = pr.K - c0 - wk * 64;
+  // rows beyond M multiply clamped (valid) columns and are masked at the store: only the one-subtile case of the
+  // final_linear rows (out_dim <= 16) is worth a variant of its own
   const int nht = __builtin_amdgcn_readfirstlane(
       (rows_left <= 0 || cols_left <= 0) ? 0 : (rows_left >= 128 ? 8 : (rows_left + 15) >> 4));
   const bf16_t *P = (const bf16_t *)pr.P, *Q = (const bf16_t *)pr.Q;
-  if (nt > 0) {
-    dw256_stage(P, pr.ldp, h0, nbeg, base, wave, lane);
-    dw256_stage(Q, pr.ldq, c0, nbeg, base + DW256_TILE, wave, lane);
+  const long nbeg = (long)tbeg * DW256_BN;
+  const int nt = tend - tbeg;
+  // Tiles k+1..k+3 are in flight while tile k is multiplied.  Per tile and thread: 4 DMA instructions, retired in order.
+#pragma unroll
+  for (int j = 0; j < DW256_NBUF - 1; ++j)
+    if (j < nt) {
+      dw256_stage(P, pr.ldp, h0, nbeg + j * DW256_BN, base + j * 2 * DW256_TILE, wave, lane);
+      dw256_stage(Q, pr.ldq, c0, nbeg + j * DW256_BN, base + j * 2 * DW256_TILE + DW256_TILE, wave, lane);
+    }
+  // slot J of a group of four works on LDS buffer J (static addresses: a run-time buffer index costs ~50 registers of
+  // per-buffer offsets and spills -- and scratch reloads are VMEM loads, which would corrupt the counted waits below)
+#define DW256_SLOT(J)                                                                                         \
+  {                                                                                                           \
+    const int k = k0 + (J);                                                                                   \
+    if (k < nt) {                                                                                             \
+      /* tile k has landed: this wave's DMAs by the counted wait (tiles k+1, k+2 stay in flight), everyone's by the */ \
+      /* barrier, which also says every wave is done reading tile k-1 -- whose buffer the DMA of tile k+3 overwrites */ \
+      if (k + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
+      else if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+      __builtin_amdgcn_s_barrier();                                                                           \
+      if (k + 3 < nt) {                                                                                       \
+        lds_char *nx = base + (((J) + 3) & 3) * 2 * DW256_TILE;                                               \
+        dw256_stage(P, pr.ldp, h0, nbeg + (long)(k + 3) * DW256_BN, nx, wave, lane);                          \
+        dw256_stage(Q, pr.ldq, c0, nbeg + (long)(k + 3) * DW256_BN, nx + DW256_TILE, wave, lane);             \
+      }                                                                                                       \
+      const lds_char *cur = base + (J) * 2 * DW256_TILE;                                                      \
+      if (nht >= 2) dw256_mma<8>(acc, cur, cur + DW256_TILE, wh, wk, lane);                                   \
+      else if (nht == 1) dw256_mma<1>(acc, cur, cur + DW256_TILE, wh, wk, lane);                              \
+    }                                                                                                         \
   }
-  for (int it = 0; it < nt; it += 2) {
-    dw256_iter(acc, base, base + 2 * DW256_TILE, P, pr.ldp, h0, Q, pr.ldq, c0, it + 1 < nt, nbeg + (long)(it + 1) * DW256_BN,
-               nht, wave, wh, wk, lane);
-    if (it + 1 >= nt) break;
-    dw256_iter(acc, base + 2 * DW256_TILE, base, P, pr.ldp, h0, Q, pr.ldq, c0, it + 2 < nt, nbeg + (long)(it + 2) * DW256_BN,
-               nht, wave, wh, wk, lane);
-  }
+  for (int k0 = 0; k0 < nt; k0 += 4) { DW256_SLOT(0) DW256_SLOT(1) DW256_SLOT(2) DW256_SLOT(3) }
+#undef DW256_SLOT
   float *slab = a.slab + ((size_t)(a.g.tile_start[pi] + t) * a.g.splitk + split) * (256 * 256);
   const int g = lane >> 4, i = lane & 15;
 #pragma unroll

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import engine as E
 from . import parallel as par
 from .models.inr_decoder import INR_Decoder
@@ -137,6 +138,11 @@ class HotPathTrainer:
                 if opt is not None:
                     self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
         self.sums = torch.zeros(4, device=self.device)
+        # second stream: the weight repacking runs beside the latent gather (independent work the one-stream order would
+        # serialise).  The weight-gradient GEMMs beside the latent-side backward were tried the same way and gain
+        # nothing: k_dw256 holds 128 KB of LDS and 432 of 512 registers per SIMD on 245 CUs, the latent-side kernels
+        # cannot become resident next to it and crawl on the remaining CUs (profiles/r01_two_stream_note.txt)
+        self.side = torch.cuda.Stream(device=self.device)
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -155,8 +161,12 @@ class HotPathTrainer:
             table = self.cond_param.data if self.cond_param is not None else st.conditions
             cond = table[subj.long()].contiguous()
         tfs = self.tfs.data
-        eng.pack()
+        main, side = torch.cuda.current_stream(self.device), self.side
+        side.wait_stream(main)                      # the previous step's optimiser wrote the parameters
+        with torch.cuda.stream(side):
+            eng.pack()
         E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
+        main.wait_stream(side)
         eng.forward(n)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
