@@ -518,6 +518,193 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// bf16 d-latent GEMM on 256 (latent features) x 128 (samples) tiles.  k_dlat's 128 x 128 tiles make every workgroup
+// pull 0.8 MB of ds / dt rows AND 0.8 MB of weights per 100 MFLOP, two workgroups per CU: 35 GB/s per CU, the rate one
+// CU gets from L2 / Infinity Cache, for 89 us.  Here one workgroup owns ALL latent features of its 128 samples (the
+// ds / dt rows are read once), operands go global -> LDS by LDS-DMA into three 48 KB buffers (two tiles in flight,
+// counted vmcnt + raw barrier as in k_dw256), fragments are plain ds_read_b128 (both operands are k-contiguous).
+// ----------------------------------------------------------------------------------------
+#define DL256_THREADS 512
+#define DL256_BK 64
+#define DL256_ROWB 128
+#define DL256_A_TILE (256 * DL256_ROWB)
+#define DL256_B_TILE (128 * DL256_ROWB)
+#define DL256_STAGE (DL256_A_TILE + DL256_B_TILE)
+#define DL256_SMEM (3 * DL256_STAGE)
+
+// A: rows f0.. of the packed [rowsA x K] weights, LDS row pr holds feature row perm(pr) (see gemm_engine.h: a lane then
+// owns 16 consecutive output features); B: rows n0.. of [n][ldB].  16-B chunk c of row r sits at position c ^ ((r>>1)&7).
+// One tile = six DMA instructions per wave: pieces 0..3 fill the A rows, 4..5 the B rows.
+struct Dl256Src { const bf16_t *A, *B; int K, f0, rowsA, ldB, k0; long n0; };
+
+template <int PIECE>
+__device__ __forceinline__ void dl256_piece(const Dl256Src &q, lds_char *dst, int wave, int lane) {
+  const int rin = lane >> 3, pos = lane & 7;
+  if constexpr (PIECE < 4) {
+    const int pr = 8 * (8 * PIECE + wave) + rin;
+    int f = q.f0 + ((pr & 128) | perm_feature_row(pr & 127));
+    f = f < q.rowsA ? f : q.rowsA - 1;
+    glds16_asm(q.A + (size_t)f * q.K + q.k0 + ((pos ^ ((pr >> 1) & 7)) << 3),
+               (unsigned)(__SIZE_TYPE__)(dst + 8 * (8 * PIECE + wave) * DL256_ROWB));
+  } else {
+    const int row = 8 * (8 * (PIECE - 4) + wave) + rin;
+    glds16_asm(q.B + (size_t)(q.n0 + row) * q.ldB + q.k0 + ((pos ^ ((row >> 1) & 7)) << 3),
+               (unsigned)(__SIZE_TYPE__)(dst + DL256_A_TILE + 8 * (8 * (PIECE - 4) + wave) * DL256_ROWB));
+  }
+}
+
+__device__ __forceinline__ void dl256_frags(bf16x8 (&af)[4], bf16x8 (&bfr)[4], const lds_char *sA, const lds_char *sB, int kk,
+                                            int wf, int wn, int lane) {
+  const int i = lane & 15, ch = kk * 4 + (lane >> 4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ra = wf * 64 + t * 16 + i, rb = wn * 64 + t * 16 + i;
+    af[t] = *(const LDS_AS bf16x8 *)(sA + ra * DL256_ROWB + ((ch ^ ((ra >> 1) & 7)) << 4));
+    bfr[t] = *(const LDS_AS bf16x8 *)(sB + rb * DL256_ROWB + ((ch ^ ((rb >> 1) & 7)) << 4));
+  }
+}
+
+__device__ __forceinline__ void dl256_mfma4(f32x4 (&acc)[4][4], const bf16x8 (&af)[4], const bf16x8 (&bfr)[4], int ft) {
+#pragma unroll
+  for (int st = 0; st < 4; ++st) acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ft], bfr[st], acc[ft][st], 0, 0, 0);
+}
+
+// Multiply one staged tile and, between the MFMA groups, issue the six DMA pieces of the tile two ahead: an LDS-DMA
+// instruction holds its wave for 60-180 cycles, which the other wave of the SIMD covers with its MFMAs only if the
+// pieces are spread out (issued in one block right after the barrier, all eight waves stall together).
+template <bool STAGE>
+__device__ __forceinline__ void dl256_tile(f32x4 (&acc)[4][4], const lds_char *sA, const lds_char *sB, const Dl256Src &q,
+                                           lds_char *dst, bool active, int wave, int wf, int wn, int lane) {
+  bf16x8 a0[4], b0[4], a1[4], b1[4];
+#define DL256_DMA(P)                                                                                          \
+  if constexpr (STAGE) {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    dl256_piece<P>(q, dst, wave, lane);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+  if (active) {
+    dl256_frags(a0, b0, sA, sB, 0, wf, wn, lane);
+    dl256_mfma4(acc, a0, b0, 0);
+    DL256_DMA(0)
+    dl256_frags(a1, b1, sA, sB, 1, wf, wn, lane);
+    dl256_mfma4(acc, a0, b0, 1);
+    DL256_DMA(1)
+    dl256_mfma4(acc, a0, b0, 2);
+    DL256_DMA(2)
+    dl256_mfma4(acc, a0, b0, 3);
+    DL256_DMA(3)
+    dl256_mfma4(acc, a1, b1, 0);
+    DL256_DMA(4)
+    dl256_mfma4(acc, a1, b1, 1);
+    DL256_DMA(5)
+    dl256_mfma4(acc, a1, b1, 2);
+    dl256_mfma4(acc, a1, b1, 3);
+  } else {
+    DL256_DMA(0) DL256_DMA(1) DL256_DMA(2) DL256_DMA(3) DL256_DMA(4) DL256_DMA(5)
+  }
+#undef DL256_DMA
+}
+
+__global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char *base = (lds_char *)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wf = wave >> 1, wn = wave & 1;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  TileCtx c;
+  c.f0 = (id % a.tiles_f) * 256;
+  c.n0 = (id / a.tiles_f) * 128;
+  c.lane = lane; c.wf = wf; c.wn = wn; c.g = lane >> 4; c.i = lane & 15;
+  c.fb = c.f0 + wf * 64 + 16 * c.g;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) c.nrow[st] = c.n0 + wn * 64 + 16 * st + c.i;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
+  const int K = a.seg[0].K, kps = K / DL256_BK;       // the host takes this path only when every segment has this K
+  const int nt = a.nseg * kps;
+  const bool wave_active = c.f0 + wf * 64 < a.LP;     // wave-uniform: feature rows of this wave exist
+  auto src_of = [&](int t) {
+    const int sg = t / kps;
+    Dl256Src q = {(const bf16_t *)a.seg[sg].A, (const bf16_t *)a.seg[sg].B, K, c.f0, a.LP, a.ldg, (t - sg * kps) * DL256_BK,
+                  (long)c.n0};
+    return q;
+  };
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (j < nt) {
+      const Dl256Src q = src_of(j);
+      lds_char *dst = base + j * DL256_STAGE;
+      dl256_piece<0>(q, dst, wave, lane); dl256_piece<1>(q, dst, wave, lane); dl256_piece<2>(q, dst, wave, lane);
+      dl256_piece<3>(q, dst, wave, lane); dl256_piece<4>(q, dst, wave, lane); dl256_piece<5>(q, dst, wave, lane);
+    }
+  // per tile and thread: 6 DMA instructions, retired in order.  At the wait of slot k tiles k and k+1 are outstanding
+  // (k+2 is issued during the multiplication below): vmcnt(6) retires tile k.
+#define DL256_SLOT(J)                                                                                         \
+  {                                                                                                           \
+    const int k = k0 + (J);                                                                                   \
+    if (k < nt) {                                                                                             \
+      if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+      __builtin_amdgcn_s_barrier();                                                                           \
+      const lds_char *sA = base + (J) * DL256_STAGE;                                                          \
+      lds_char *dst = base + (((J) + 2) % 3) * DL256_STAGE;                                                   \
+      if (k + 2 < nt) {                                                                                       \
+        const Dl256Src q = src_of(k + 2);                                                                     \
+        dl256_tile<true>(acc, sA, sA + DL256_A_TILE, q, dst, wave_active, wave, wf, wn, lane);                \
+      } else {                                                                                                \
+        const Dl256Src q = {};                                                                                \
+        dl256_tile<false>(acc, sA, sA + DL256_A_TILE, q, dst, wave_active, wave, wf, wn, lane);               \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+  for (int k0 = 0; k0 < nt; k0 += 3) { DL256_SLOT(0) DL256_SLOT(1) DL256_SLOT(2) }
+#undef DL256_SLOT
+  // The fp32 small-K term (dOut x final_linear.weight[:, H:], K = out_dim <= 16) goes last -- its ordinary loads must
+  // not sit between the hand-counted DMAs above -- and through LDS: read per lane straight from global memory it is a
+  // chain of dependent, uncoalesced round trips (a third of this kernel's time when it was).
+  __syncthreads();
+  {
+    LDS_AS float *wl = (LDS_AS float *)base;            // [ks][256]: weight of latent feature f0 + l against output k
+    LDS_AS float *xl = wl + 16 * 256;                   // [128][16]: dOut rows of the tile
+    for (int q = tid; q < a.ks * 256; q += DL256_THREADS) {
+      const int k = q >> 8, f = c.f0 + (q & 255);
+      wl[q] = f < a.lat ? a.Ws[(size_t)f * a.ws_sf + (size_t)k * a.ws_sk] : 0.f;
+    }
+    for (int q = tid; q < 128 * a.ks; q += DL256_THREADS) {
+      const int n = q / a.ks, k = q - n * a.ks;
+      xl[n * 16 + k] = a.Xs[(size_t)(c.n0 + n) * a.ldxs + k];
+    }
+    __syncthreads();
+    if (c.fb < a.LP)
+      for (int k = 0; k < a.ks; ++k) {
+        float xv[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) xv[st] = xl[(wn * 64 + 16 * st + c.i) * 16 + k];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 w = *(const LDS_AS f32x4 *)(wl + k * 256 + wf * 64 + 16 * c.g + 4 * q4);
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q4][st][r] += w[r] * xv[st];
+        }
+      }
+  }
+  if (c.fb < a.LP) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = acc[j >> 2][st][j & 3];
+      store16(a.out + (size_t)c.nrow[st] * a.LP + c.fb, v);
+    }
+  }
+}
+
 // out[h][k] = sum over the splits of one tile; block = 8 rows of one tile, thread = 8 columns
 __global__ __launch_bounds__(256) void k_dw256_reduce(Dw256Args a) {
   const int tg = blockIdx.x >> 5, rb = blockIdx.x & 31;
@@ -988,16 +1175,32 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     a.Xs = dout; a.ldxs = d->out_dim; a.ks = d->out_dim;
     a.Ws = params + d->off_wf + H; a.ws_sf = 1; a.ws_sk = H + L;
     a.lat = L; a.LP = LP; a.ldg = HP; a.out = dlat;
-    a.tiles_f = (LP + 127) / 128;
-    const int g2 = a.tiles_f * (int)(Npad / 128);
-    constexpr int smem = Engine<T>::NT_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (int rc = set_smem_attr<T>((const void *)k_dlat<T>, smem)) return rc;
-      attr_done = true;
+    bool wide = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (LP >= 192 && Npad >= 4096 && ns > 0 && HP % DL256_BK == 0) {
+        wide = true;
+        a.tiles_f = (LP + 255) / 256;
+        static bool attr256 = false;
+        if (!attr256) {
+          CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_dlat256, hipFuncAttributeMaxDynamicSharedMemorySize, DL256_SMEM));
+          attr256 = true;
+        }
+        hipLaunchKernelGGL(k_dlat256, dim3(a.tiles_f * (int)(Npad / 128)), dim3(DL256_THREADS), DL256_SMEM, s, a);
+        CINEMA_CHECK_HIP(hipGetLastError());
+      }
     }
-    hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
-    CINEMA_CHECK_HIP(hipGetLastError());
+    if (!wide) {
+      a.tiles_f = (LP + 127) / 128;
+      const int g2 = a.tiles_f * (int)(Npad / 128);
+      constexpr int smem = Engine<T>::NT_SMEM;
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (int rc = set_smem_attr<T>((const void *)k_dlat<T>, smem)) return rc;
+        attr_done = true;
+      }
+      hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
+      CINEMA_CHECK_HIP(hipGetLastError());
+    }
   }
   if (!wgrads) return 0;
 

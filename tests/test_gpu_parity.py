@@ -228,6 +228,15 @@ def test_oracle_parity_wide_ragged_256_tiles():
     assert not bad, f"{bad}\nall: {errs}"
 
 
+def test_oracle_parity_wide_latent_257():
+    """bf16, latent 256 + 1 condition = 257 (LP = 320: the 256-row d-latent tile plus a 64-row remainder tile whose upper
+    waves idle), hidden 256, N = 4200."""
+    errs = _oracle_case(N=4200, S=5, latent_dim=[256, 1, 1, 1], hidden=256, layers=2, mod=[1, 2], out_dim=[1, 6], cond=1,
+                        seed=29, precision="bf16", tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_oracle_parity_large_batch_grouping_path():
     """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
     errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,
