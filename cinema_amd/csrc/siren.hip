@@ -525,7 +525,7 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
 // ds / dt rows are read once), operands go global -> LDS by LDS-DMA into three 48 KB buffers (two tiles in flight,
 // counted vmcnt + raw barrier as in k_dw256), fragments are plain ds_read_b128 (both operands are k-contiguous).
 // ----------------------------------------------------------------------------------------
-#define DL256_THREADS 512
+#define DL256_THREADS 768                         // 8 multiply waves + 4 loader waves
 #define DL256_BK 64
 #define DL256_ROWB 128
 #define DL256_A_TILE (256 * DL256_ROWB)
@@ -535,22 +535,26 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
 
 // A: rows f0.. of the packed [rowsA x K] weights, LDS row pr holds feature row perm(pr) (see gemm_engine.h: a lane then
 // owns 16 consecutive output features); B: rows n0.. of [n][ldB].  16-B chunk c of row r sits at position c ^ ((r>>1)&7).
-// One tile = six DMA instructions per wave: pieces 0..3 fill the A rows, 4..5 the B rows.
+// One tile = 48 DMA instructions of 1 KB (8 rows): 32 for the A rows, 16 for the B rows; loader wave d issues the
+// instructions d, d + 4, ... (12 per tile).
 struct Dl256Src { const bf16_t *A, *B; int K, f0, rowsA, ldB, k0; long n0; };
 
-template <int PIECE>
-__device__ __forceinline__ void dl256_piece(const Dl256Src &q, lds_char *dst, int wave, int lane) {
+__device__ __forceinline__ void dl256_load_tile(const Dl256Src &q, lds_char *dst, int d, int lane) {
   const int rin = lane >> 3, pos = lane & 7;
-  if constexpr (PIECE < 4) {
-    const int pr = 8 * (8 * PIECE + wave) + rin;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int blk = d + 4 * j;                       // 8-row block 0..31 of the A tile
+    const int pr = 8 * blk + rin;
     int f = q.f0 + ((pr & 128) | perm_feature_row(pr & 127));
     f = f < q.rowsA ? f : q.rowsA - 1;
-    glds16_asm(q.A + (size_t)f * q.K + q.k0 + ((pos ^ ((pr >> 1) & 7)) << 3),
-               (unsigned)(__SIZE_TYPE__)(dst + 8 * (8 * PIECE + wave) * DL256_ROWB));
-  } else {
-    const int row = 8 * (8 * (PIECE - 4) + wave) + rin;
+    glds16_asm(q.A + (size_t)f * q.K + q.k0 + ((pos ^ ((pr >> 1) & 7)) << 3), (unsigned)(__SIZE_TYPE__)(dst + 8 * blk * DL256_ROWB));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int blk = d + 4 * j;                       // 8-row block 0..15 of the B tile
+    const int row = 8 * blk + rin;
     glds16_asm(q.B + (size_t)(q.n0 + row) * q.ldB + q.k0 + ((pos ^ ((row >> 1) & 7)) << 3),
-               (unsigned)(__SIZE_TYPE__)(dst + DL256_A_TILE + 8 * (8 * (PIECE - 4) + wave) * DL256_ROWB));
+               (unsigned)(__SIZE_TYPE__)(dst + DL256_A_TILE + 8 * blk * DL256_ROWB));
   }
 }
 
@@ -565,52 +569,17 @@ __device__ __forceinline__ void dl256_frags(bf16x8 (&af)[4], bf16x8 (&bfr)[4], c
   }
 }
 
-__device__ __forceinline__ void dl256_mfma4(f32x4 (&acc)[4][4], const bf16x8 (&af)[4], const bf16x8 (&bfr)[4], int ft) {
-#pragma unroll
-  for (int st = 0; st < 4; ++st) acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ft], bfr[st], acc[ft][st], 0, 0, 0);
-}
-
-// Multiply one staged tile and, between the MFMA groups, issue the six DMA pieces of the tile two ahead: an LDS-DMA
-// instruction holds its wave for 60-180 cycles, which the other wave of the SIMD covers with its MFMAs only if the
-// pieces are spread out (issued in one block right after the barrier, all eight waves stall together).
-template <bool STAGE>
-__device__ __forceinline__ void dl256_tile(f32x4 (&acc)[4][4], const lds_char *sA, const lds_char *sB, const Dl256Src &q,
-                                           lds_char *dst, bool active, int wave, int wf, int wn, int lane) {
-  bf16x8 a0[4], b0[4], a1[4], b1[4];
-#define DL256_DMA(P)                                                                                          \
-  if constexpr (STAGE) {                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    dl256_piece<P>(q, dst, wave, lane);                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-  }
-  if (active) {
-    dl256_frags(a0, b0, sA, sB, 0, wf, wn, lane);
-    dl256_mfma4(acc, a0, b0, 0);
-    DL256_DMA(0)
-    dl256_frags(a1, b1, sA, sB, 1, wf, wn, lane);
-    dl256_mfma4(acc, a0, b0, 1);
-    DL256_DMA(1)
-    dl256_mfma4(acc, a0, b0, 2);
-    DL256_DMA(2)
-    dl256_mfma4(acc, a0, b0, 3);
-    DL256_DMA(3)
-    dl256_mfma4(acc, a1, b1, 0);
-    DL256_DMA(4)
-    dl256_mfma4(acc, a1, b1, 1);
-    DL256_DMA(5)
-    dl256_mfma4(acc, a1, b1, 2);
-    dl256_mfma4(acc, a1, b1, 3);
-  } else {
-    DL256_DMA(0) DL256_DMA(1) DL256_DMA(2) DL256_DMA(3) DL256_DMA(4) DL256_DMA(5)
-  }
-#undef DL256_DMA
-}
-
+// Waves 0..7 multiply (4 x 2 wave tiles of 64 features x 64 samples), waves 8..11 only move data: an LDS-DMA
+// instruction holds its wave for ~100 cycles (the CU's address path takes 64 B per clock), and eight waves that all
+// stage and then all multiply after the same barrier add the two times up (measured: 21 us of MFMA + 19 us of DMA issue
+// side by side).  With the loaders on their own waves the multiply waves never wait for an address.
 __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *base = (lds_char *)smem;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wf = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 8;
+  const int wf = (wave >> 1) & 3, wn = wave & 1;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   TileCtx c;
   c.f0 = (id % a.tiles_f) * 256;
@@ -619,53 +588,56 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   c.fb = c.f0 + wf * 64 + 16 * c.g;
 #pragma unroll
   for (int st = 0; st < 4; ++st) c.nrow[st] = c.n0 + wn * 64 + 16 * st + c.i;
+  const int K = a.seg[0].K, kps = K / DL256_BK;       // the host takes this path only when every segment has this K
+  const int nt = a.nseg * kps;
   f32x4 acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[x][y] = z; }
-  const int K = a.seg[0].K, kps = K / DL256_BK;       // the host takes this path only when every segment has this K
-  const int nt = a.nseg * kps;
-  const bool wave_active = c.f0 + wf * 64 < a.LP;     // wave-uniform: feature rows of this wave exist
-  auto src_of = [&](int t) {
-    const int sg = t / kps;
-    Dl256Src q = {(const bf16_t *)a.seg[sg].A, (const bf16_t *)a.seg[sg].B, K, c.f0, a.LP, a.ldg, (t - sg * kps) * DL256_BK,
-                  (long)c.n0};
-    return q;
-  };
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    if (j < nt) {
-      const Dl256Src q = src_of(j);
-      lds_char *dst = base + j * DL256_STAGE;
-      dl256_piece<0>(q, dst, wave, lane); dl256_piece<1>(q, dst, wave, lane); dl256_piece<2>(q, dst, wave, lane);
-      dl256_piece<3>(q, dst, wave, lane); dl256_piece<4>(q, dst, wave, lane); dl256_piece<5>(q, dst, wave, lane);
+  if (loader) {
+    const int d = wave - 8;
+    auto src_of = [&](int t) {
+      const int sg = t / kps;
+      Dl256Src q = {(const bf16_t *)a.seg[sg].A, (const bf16_t *)a.seg[sg].B, K, c.f0, a.LP, a.ldg, (t - sg * kps) * DL256_BK,
+                    (long)c.n0};
+      return q;
+    };
+    if (nt > 0) dl256_load_tile(src_of(0), base, d, lane);
+    if (nt > 1) dl256_load_tile(src_of(1), base + DL256_STAGE, d, lane);
+    // 12 DMA instructions per tile and loader wave, retired in order: at the wait of tile k the tiles k and k+1 are
+    // outstanding.  The barrier tells the multiply waves that tile k is complete and tells this wave that they are
+    // done with tile k-1, whose buffer tile k+2 overwrites.
+    for (int k = 0; k < nt; ++k) {
+      if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (k + 2 < nt) dl256_load_tile(src_of(k + 2), base + ((k + 2) % 3) * DL256_STAGE, d, lane);
     }
-  // per tile and thread: 6 DMA instructions, retired in order.  At the wait of slot k tiles k and k+1 are outstanding
-  // (k+2 is issued during the multiplication below): vmcnt(6) retires tile k.
+  } else {
+    const bool wave_active = c.f0 + wf * 64 < a.LP;   // wave-uniform: feature rows of this wave exist
 #define DL256_SLOT(J)                                                                                         \
-  {                                                                                                           \
-    const int k = k0 + (J);                                                                                   \
-    if (k < nt) {                                                                                             \
-      if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-      __builtin_amdgcn_s_barrier();                                                                           \
-      const lds_char *sA = base + (J) * DL256_STAGE;                                                          \
-      lds_char *dst = base + (((J) + 2) % 3) * DL256_STAGE;                                                   \
-      if (k + 2 < nt) {                                                                                       \
-        const Dl256Src q = src_of(k + 2);                                                                     \
-        dl256_tile<true>(acc, sA, sA + DL256_A_TILE, q, dst, wave_active, wave, wf, wn, lane);                \
-      } else {                                                                                                \
-        const Dl256Src q = {};                                                                                \
-        dl256_tile<false>(acc, sA, sA + DL256_A_TILE, q, dst, wave_active, wave, wf, wn, lane);               \
-      }                                                                                                       \
+  if (k0 + (J) < nt) {                                                                                        \
+    __builtin_amdgcn_s_barrier();                                                                             \
+    if (wave_active) {                                                                                        \
+      const lds_char *sA = base + (J) * DL256_STAGE, *sB = sA + DL256_A_TILE;                                 \
+      bf16x8 a0[4], b0[4], a1[4], b1[4];                                                                      \
+      dl256_frags(a0, b0, sA, sB, 0, wf, wn, lane);                                                           \
+      dl256_frags(a1, b1, sA, sB, 1, wf, wn, lane);                                                           \
+      _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                        \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                      \
+          acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[ft], b0[st], acc[ft][st], 0, 0, 0);        \
+      _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                        \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                      \
+          acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ft], b1[st], acc[ft][st], 0, 0, 0);        \
     }                                                                                                         \
   }
-  for (int k0 = 0; k0 < nt; k0 += 3) { DL256_SLOT(0) DL256_SLOT(1) DL256_SLOT(2) }
+    for (int k0 = 0; k0 < nt; k0 += 3) { DL256_SLOT(0) DL256_SLOT(1) DL256_SLOT(2) }
 #undef DL256_SLOT
+  }
   // The fp32 small-K term (dOut x final_linear.weight[:, H:], K = out_dim <= 16) goes last -- its ordinary loads must
   // not sit between the hand-counted DMAs above -- and through LDS: read per lane straight from global memory it is a
-  // chain of dependent, uncoalesced round trips (a third of this kernel's time when it was).
+  // chain of dependent, uncoalesced round trips.
   __syncthreads();
   {
     LDS_AS float *wl = (LDS_AS float *)base;            // [ks][256]: weight of latent feature f0 + l against output k
@@ -679,6 +651,7 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
       xl[n * 16 + k] = a.Xs[(size_t)(c.n0 + n) * a.ldxs + k];
     }
     __syncthreads();
+    if (loader) return;
     if (c.fb < a.LP)
       for (int k = 0; k < a.ks; ++k) {
         float xv[4];
