@@ -12,6 +12,8 @@ import os
 MAX_LAYERS = 16
 PREC_F32, PREC_BF16 = 0, 1
 BWD_SKIP_WEIGHT_GRADS = 1
+BWD_GRADS_CLEARED, BWD_DCOORDS_CLEARED = 2, 64
+PREPARE_SCRATCH = 260
 BWD_PHASE_CHAIN, BWD_PHASE_DLAT, BWD_PHASE_DW, BWD_PHASE_FINAL_DW = 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +61,8 @@ SIGNATURES = {
     "cinema_affine_trilerp_bwd_sorted": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                          _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
+    "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
+    "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],
     "cinema_infer_minmax": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_infer_finish": [_P, _I64, _I32, _I32, _P, _P, _P],
 }
@@ -111,3 +115,4 @@ class AdamWGroup(C.Structure):
 
 
 SIGNATURES["cinema_adamw_step"] = [C.POINTER(AdamWGroup), _I32, _P]
+SIGNATURES["cinema_adamw_step_clear"] = [C.POINTER(AdamWGroup), _I32, _P]

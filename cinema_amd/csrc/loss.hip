@@ -25,6 +25,48 @@ __global__ void k_class_weight_sum(const float *target, int tcols, const int64_t
   if ((threadIdx.x & 63) == 0) atomicAdd(sums + 2, acc);
 }
 
+// Per-step clearing + class-weight normaliser in ONE launch: every workgroup zeroes its share of dcoords and leaves the
+// partial sum of w[label] over its samples in scratch; the workgroup that finishes last (a counter in scratch, which it
+// resets for the next call) adds the partials in workgroup order and writes sums = {0, 0, sum w, 0}.  No zero-then-
+// accumulate ordering between launches, no float atomics: the same bits every run.
+#define PREP_MAX_GRID 256
+__global__ __launch_bounds__(256) void k_step_prepare(float *dcoords, long n_dcoords, float *sums, const int64_t *voxel,
+                                                      const int32_t *subj, const uint8_t *labels, long V, long N, int n_cls,
+                                                      const float *class_w, float *scratch) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  if (class_w != nullptr) {
+    for (long n = (long)blockIdx.x * blockDim.x + tid; n < N; n += (long)gridDim.x * blockDim.x) {
+      int y = (int)labels[(long)subj[n] * V + voxel[n]];
+      y = y < 0 ? 0 : (y >= n_cls ? n_cls - 1 : y);
+      acc += class_w[y];
+    }
+  }
+  for (long e = (long)blockIdx.x * blockDim.x + tid; e < n_dcoords; e += (long)gridDim.x * blockDim.x) dcoords[e] = 0.f;
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  unsigned int *counter = reinterpret_cast<unsigned int *>(scratch + PREP_MAX_GRID);
+  if (tid == 0) {
+    scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    __threadfence();
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && tid < 64) {
+    __threadfence();
+    float t = 0.f;
+    for (int b = tid; b < (int)gridDim.x; b += 64) t += __builtin_nontemporal_load(scratch + b);
+    t = wave_sum(t);
+    if (tid == 0) {
+      sums[0] = 0.f; sums[1] = 0.f; sums[2] = t; sums[3] = 0.f;
+      *counter = 0u;
+    }
+  }
+}
+
 struct LossArgs {
   const float *out; const float *target; const int64_t *voxel; const int32_t *subj; const float *intens;
   const uint8_t *labels; long V, N, Npad; int sr_dims, n_cls, metric; const float *class_w;
@@ -165,21 +207,21 @@ __global__ void k_infer_finish(const float *out, long G, int od, int sr, const f
 
 }  // namespace
 
-extern "C" int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
-                                          const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
-                                          int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
-                                          float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
-                                          void *stream) {
+static int sample_loss_impl(bool prepared, const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                            const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                            int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                            float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                            void *stream) {
   CINEMA_REQUIRE(out && sums && dout, "cinema_sample_loss_fwd_bwd: null argument");
   CINEMA_REQUIRE(target || (voxel && subj && intens && labels), "cinema_sample_loss_fwd_bwd: need a dense target or volumes");
   CINEMA_REQUIRE(N >= 1 && Npad >= N, "cinema_sample_loss_fwd_bwd: bad sizes");
   CINEMA_REQUIRE(sr_dims >= 1 && sr_dims <= 8 && n_cls >= 1 && n_cls <= 16, "unsupported out_dim split %d + %d", sr_dims, n_cls);
   CINEMA_REQUIRE(loss_metric == 0 || loss_metric == 1, "loss_metric must be 0 (mse) or 1 (l1)");
   hipStream_t s = (hipStream_t)stream;
-  CINEMA_CHECK_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(float), s));
+  if (!prepared) CINEMA_CHECK_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(float), s));
   const unsigned grid = (unsigned)std::min<long>((Npad + 255) / 256, 2048);
   const int wdev = (class_w != nullptr && seg_scale > 0.f) ? 1 : 0;
-  if (wdev) {
+  if (wdev && !prepared) {
     hipLaunchKernelGGL(k_class_weight_sum, dim3(grid), dim3(256), 0, s, target, sr_dims + 1, voxel, subj, labels, (long)V,
                        (long)N, n_cls, class_w, sums);
     CINEMA_CHECK_HIP(hipGetLastError());
@@ -187,6 +229,39 @@ extern "C" int cinema_sample_loss_fwd_bwd(const float *out, const float *target,
   LossArgs a = {out, target, voxel, subj, intens, labels, (long)V, (long)N, (long)Npad, sr_dims, n_cls, loss_metric, class_w,
                 sr_scale, seg_scale, sums, dout, target_out, wdev};
   hipLaunchKernelGGL(k_sample_loss<16>, dim3(grid), dim3(256), 0, s, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                                          const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                                          int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                                          float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                                          void *stream) {
+  return sample_loss_impl(false, out, target, voxel, subj, intens, labels, V, N, Npad, sr_dims, n_cls, loss_metric, class_w,
+                          sr_scale, seg_scale, sums, dout, target_out, stream);
+}
+
+extern "C" int cinema_sample_loss_fwd_bwd_prepared(const float *out, const float *target, const int64_t *voxel,
+                                                   const int32_t *subj, const float *intens, const uint8_t *labels, int64_t V,
+                                                   int64_t N, int64_t Npad, int32_t sr_dims, int32_t n_cls, int32_t loss_metric,
+                                                   const float *class_w, float sr_scale, float seg_scale, float *sums,
+                                                   float *dout, float *target_out, void *stream) {
+  return sample_loss_impl(true, out, target, voxel, subj, intens, labels, V, N, Npad, sr_dims, n_cls, loss_metric, class_w,
+                          sr_scale, seg_scale, sums, dout, target_out, stream);
+}
+
+extern "C" int cinema_step_prepare(float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const int32_t *subj,
+                                   const uint8_t *labels, int64_t V, int64_t N, int32_t n_cls, const float *class_w,
+                                   float *scratch, void *stream) {
+  CINEMA_REQUIRE(sums != nullptr && scratch != nullptr && n_dcoords >= 0 && (dcoords != nullptr || n_dcoords == 0),
+                 "cinema_step_prepare: bad argument");
+  CINEMA_REQUIRE(class_w == nullptr || (voxel && subj && labels && N >= 1 && n_cls >= 1),
+                 "cinema_step_prepare: class_w needs the label source");
+  const long work = std::max<long>(class_w != nullptr ? (long)N : 0, (long)n_dcoords);
+  const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
+  hipLaunchKernelGGL(k_step_prepare, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcoords, (long)n_dcoords, sums, voxel, subj,
+                     labels, (long)V, (long)N, n_cls, class_w, scratch);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -11,7 +11,7 @@ namespace {
 struct AdamArgs {
   cinema_adamw_group g[CINEMA_ADAMW_MAX_GROUPS];
   float bc1[CINEMA_ADAMW_MAX_GROUPS], bc2_rsqrt[CINEMA_ADAMW_MAX_GROUPS];
-  int n_groups;
+  int n_groups, clear_grads;
 };
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const cinema_adamw_group &c, float step_size,
@@ -46,16 +46,19 @@ __global__ __launch_bounds__(256) void k_adamw(AdamArgs a) {
       reinterpret_cast<f32x4 *>(c.p)[i] = p;
       reinterpret_cast<f32x4 *>(c.m)[i] = m;
       reinterpret_cast<f32x4 *>(c.v)[i] = v;
+      if (a.clear_grads) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; reinterpret_cast<f32x4 *>(const_cast<float *>(c.g))[i] = z; }
     }
     done = n4 << 2;
   }
-  for (long i = done + (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += (long)gridDim.x * blockDim.x)
+  for (long i = done + (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += (long)gridDim.x * blockDim.x) {
     adam_one(c.p[i], c.g[i], c.m[i], c.v[i], c, step_size, r2);
+    if (a.clear_grads) const_cast<float *>(c.g)[i] = 0.f;
+  }
 }
 
 }  // namespace
 
-extern "C" int cinema_adamw_step(const cinema_adamw_group *groups, int32_t n_groups, void *stream) {
+static int adamw_impl(const cinema_adamw_group *groups, int32_t n_groups, int clear_grads, void *stream) {
   CINEMA_REQUIRE(groups != nullptr && n_groups >= 1 && n_groups <= CINEMA_ADAMW_MAX_GROUPS,
                  "cinema_adamw_step: need 1..%d groups", CINEMA_ADAMW_MAX_GROUPS);
   AdamArgs a = {};
@@ -69,9 +72,18 @@ extern "C" int cinema_adamw_step(const cinema_adamw_group *groups, int32_t n_gro
     nmax = std::max<long>(nmax, g.n);
   }
   a.n_groups = n_groups;
+  a.clear_grads = clear_grads;
   if (nmax == 0) return 0;
   const unsigned gx = (unsigned)std::min<long>((nmax / 4 + 255) / 256 + 1, 2048);
   hipLaunchKernelGGL(k_adamw, dim3(gx, n_groups), dim3(256), 0, (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int cinema_adamw_step(const cinema_adamw_group *groups, int32_t n_groups, void *stream) {
+  return adamw_impl(groups, n_groups, 0, stream);
+}
+
+extern "C" int cinema_adamw_step_clear(const cinema_adamw_group *groups, int32_t n_groups, void *stream) {
+  return adamw_impl(groups, n_groups, 1, stream);
 }

@@ -1085,8 +1085,9 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   const size_t slot = (size_t)Npad * HP;
   const int tiles_f = (HP + 127) / 128;
   const int grid = tiles_f * (int)(Npad / 128);
-  if (wgrads && all_phases) CINEMA_CHECK_HIP(hipMemsetAsync(gp, 0, sizeof(float) * (size_t)d->n_params, s));
-  if (phases & CINEMA_BWD_PHASE_CHAIN)
+  if (wgrads && all_phases && !(flags & CINEMA_BWD_GRADS_CLEARED))
+    CINEMA_CHECK_HIP(hipMemsetAsync(gp, 0, sizeof(float) * (size_t)d->n_params, s));
+  if ((phases & CINEMA_BWD_PHASE_CHAIN) && !(flags & CINEMA_BWD_DCOORDS_CLEARED))
     CINEMA_CHECK_HIP(hipMemsetAsync(dcoords, 0, sizeof(float) * (size_t)Npad * d->in_dim, s));
 
   // ---- chain ----

@@ -113,6 +113,7 @@ class SirenEngine:
         self.packed = torch.zeros(desc.pk_total, device=device, dtype=pk_dt)
         self.ws: Optional[Workspace] = None
         self.version = 0          # bumped by every forward: guards stale backward calls
+        self.grads_clean = True   # flat_grad holds zeros (a clearing optimiser step ran after the last backward)
         self._packed_version = None
 
     # -- views ------------------------------------------------------------------------
@@ -157,12 +158,21 @@ class SirenEngine:
               "cinema_siren_forward")
         return ws.out
 
-    def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0):
-        """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords."""
+    def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0,
+                 dcoords_cleared: bool = False):
+        """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords.
+        dcoords_cleared: ws.dcoords already holds zeros (step_prepare); flat_grad is not cleared again when a
+        clearing optimiser step left it zeroed (grads_clean)."""
         ws = self.ws
         ws.ensure_backward()
         npad = round_up(n, ROW_ALIGN)
         flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | phases
+        if dcoords_cleared:
+            flags |= _lib.BWD_DCOORDS_CLEARED
+        if weight_grads:
+            if self.grads_clean and phases == 0:
+                flags |= _lib.BWD_GRADS_CLEARED
+            self.grads_clean = False
         check(self.lib.cinema_siren_backward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
                                              ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n, npad, ptr(ws.gbuf),
                                              ptr(self.flat_grad), ptr(ws.dlat), ptr(ws.dcoords), flags, self.stream()),
@@ -247,13 +257,29 @@ def sample_loss(eng_or_device, out: torch.Tensor, n: int, sr_dims: int, n_cls: i
                 sums: torch.Tensor, target: Optional[torch.Tensor] = None, voxel: Optional[torch.Tensor] = None,
                 subj: Optional[torch.Tensor] = None, intens: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, voxels_per_subject: int = 0,
-                target_out: Optional[torch.Tensor] = None):
-    """K3: GT sampling + loss sums + dLoss/dOutput in one launch (see include/cinema_hip.h)."""
+                target_out: Optional[torch.Tensor] = None, prepared: bool = False):
+    """K3: GT sampling + loss sums + dLoss/dOutput in one launch (see include/cinema_hip.h).
+    prepared: `sums` was set up by step_prepare (no memset, no class-weight pre-pass)."""
     lib = _lib.load()
     device = out.device
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     npad = min(round_up(n, ROW_ALIGN), dout.shape[0])
-    check(lib.cinema_sample_loss_fwd_bwd(ptr(out), ptr(target), ptr(voxel), ptr(subj), ptr(intens), ptr(labels),
-                                         voxels_per_subject, n, npad, sr_dims, n_cls, 0 if loss_metric == "mse" else 1,
-                                         ptr(class_w), float(sr_scale), float(seg_scale), ptr(sums), ptr(dout),
-                                         ptr(target_out), stream), "cinema_sample_loss_fwd_bwd")
+    fn = lib.cinema_sample_loss_fwd_bwd_prepared if prepared else lib.cinema_sample_loss_fwd_bwd
+    check(fn(ptr(out), ptr(target), ptr(voxel), ptr(subj), ptr(intens), ptr(labels),
+             voxels_per_subject, n, npad, sr_dims, n_cls, 0 if loss_metric == "mse" else 1,
+             ptr(class_w), float(sr_scale), float(seg_scale), ptr(sums), ptr(dout),
+             ptr(target_out), stream), "cinema_sample_loss_fwd_bwd")
+
+
+def step_prepare(dcoords: Optional[torch.Tensor], sums: torch.Tensor, n: int, n_cls: int,
+                 class_w: Optional[torch.Tensor], voxel: Optional[torch.Tensor], subj: Optional[torch.Tensor],
+                 labels: Optional[torch.Tensor], voxels_per_subject: int, scratch: torch.Tensor):
+    """Per-step clearing (dcoords, loss sums) + the class-weight normaliser of the batch in one launch on the
+    CURRENT stream (the trainer runs it on its side stream, beside the forward).
+    scratch: fp32 [_lib.PREPARE_SCRATCH], zeroed once at allocation."""
+    if scratch.numel() < _lib.PREPARE_SCRATCH or scratch.dtype != torch.float32:
+        raise ValueError("step_prepare: scratch must be fp32 with at least PREPARE_SCRATCH entries")
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(sums.device).cuda_stream)
+    check(lib.cinema_step_prepare(ptr(dcoords), 0 if dcoords is None else dcoords.numel(), ptr(sums), ptr(voxel), ptr(subj),
+                                  ptr(labels), voxels_per_subject, n, n_cls, ptr(class_w), ptr(scratch), stream), "cinema_step_prepare")

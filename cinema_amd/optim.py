@@ -12,9 +12,11 @@ from . import _lib
 
 
 class HipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clear_grads=False):
+        """clear_grads: step() leaves the gradients zeroed (step + the next zero_grad in one pass over them)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._lib = _lib.load()
+        self.clear_grads = bool(clear_grads)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -41,5 +43,6 @@ class HipAdamW(torch.optim.Optimizer):
             chunk = entries[i:i + _lib.ADAMW_MAX_GROUPS]
             arr = (_lib.AdamWGroup * len(chunk))(*[e[0] for e in chunk])
             stream = C.c_void_p(torch.cuda.current_stream(chunk[0][1]).cuda_stream)
-            _lib.check(self._lib.cinema_adamw_step(arr, len(chunk), stream), "cinema_adamw_step")
+            fn = self._lib.cinema_adamw_step_clear if self.clear_grads else self._lib.cinema_adamw_step
+            _lib.check(fn(arr, len(chunk), stream), "cinema_adamw_step")
         return None

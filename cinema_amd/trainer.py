@@ -88,10 +88,13 @@ class SubjectStore:
 
 class HotPathTrainer:
     def __init__(self, args: dict, store: SubjectStore, device, process_group=None, split: str = "train",
-                 decoder: Optional[INR_Decoder] = None):
+                 decoder: Optional[INR_Decoder] = None, keep_grads: bool = False):
+        """keep_grads=True leaves the step's gradients in lat_grad / tf_grad / eng.flat_grad for inspection; by default the
+        optimiser launch zeroes them as it consumes them (the next step then needs no zero_grad fill)."""
         import torch.distributed as dist
         self.args, self.store, self.device, self.split = args, store, torch.device(device), split
         self.pg = process_group
+        self.keep_grads = bool(keep_grads)
         self.rank, self.world = par.world_info(process_group)
         a, o = args["inr_decoder"], args["optimizer"]
         self.sr_dims = sum(a["out_dim"][:-1])
@@ -126,11 +129,11 @@ class HotPathTrainer:
         mlp_group = {"params": [self.flat_param], "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}
         if self.train_mlp and self.world == 1:
             # one process: nothing to wait for between the table-side and the MLP update -> one launch for all groups
-            self.opt_local = HipAdamW(groups + [mlp_group])
+            self.opt_local = HipAdamW(groups + [mlp_group], clear_grads=not self.keep_grads)
             self.opt_mlp = None
         else:
-            self.opt_local = HipAdamW(groups)
-            self.opt_mlp = HipAdamW([mlp_group]) if self.train_mlp else None
+            self.opt_local = HipAdamW(groups, clear_grads=not self.keep_grads)
+            self.opt_mlp = HipAdamW([mlp_group], clear_grads=not self.keep_grads) if self.train_mlp else None
         self.schedulers = []
         if o.get("scheduler", {}).get("type") == "cosine":
             T = args["epochs"][split]
@@ -142,7 +145,11 @@ class HotPathTrainer:
         # serialise).  The weight-gradient GEMMs beside the latent-side backward were tried the same way and gain
         # nothing: k_dw256 holds 128 KB of LDS and 432 of 512 registers per SIMD on 245 CUs, the latent-side kernels
         # cannot become resident next to it and crawl on the remaining CUs (profiles/r01_two_stream_note.txt)
+        # The same stream carries the per-step clearing (registered-coordinate gradient, loss sums) and the class-weight
+        # normaliser of the batch, none of which depends on the forward; the optimiser leaves the gradients zeroed.
+        # Together: four fills and the class-weight pre-pass (25 us) leave the critical path of a step.
         self.side = torch.cuda.Stream(device=self.device)
+        self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -163,15 +170,18 @@ class HotPathTrainer:
         tfs = self.tfs.data
         main, side = torch.cuda.current_stream(self.device), self.side
         side.wait_stream(main)                      # the previous step's optimiser wrote the parameters
+        use_cw = self.class_w is not None and self.seg_weight > 0
         with torch.cuda.stream(side):
+            E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
+                           self.prep_scratch)
             eng.pack()
         E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
-        main.wait_stream(side)
+        main.wait_stream(side)                      # ONE join: every cross-stream wait costs ~6 us of idle queue
         eng.forward(n)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
-                      labels=st.labels, voxels_per_subject=st.V)
-        eng.backward(n, ws.dout, weight_grads=self.train_mlp)
+                      labels=st.labels, voxels_per_subject=st.V, prepared=True)
+        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True)
         work = None
         if self.train_mlp and self.world > 1:
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
@@ -195,6 +205,8 @@ class HotPathTrainer:
             work.wait()
         if self.opt_mlp is not None:
             self.opt_mlp.step()
+        if self.train_mlp and not self.keep_grads:
+            eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
         self.n_last = n
 
     def _add_tf_regulariser_grad(self, subj, n):

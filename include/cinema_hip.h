@@ -42,6 +42,11 @@ extern "C" {
 #define CINEMA_BWD_PHASE_DW 16       /* grouped weight-gradient GEMMs (one launch) */
 #define CINEMA_BWD_PHASE_FINAL_DW 32 /* final_linear weight / bias gradients */
 #define CINEMA_BWD_PHASE_MASK 60
+/* The caller already holds zeros in grad_params / in dcoords (a training loop clears them off the critical path:
+ * cinema_adamw_step_clear leaves zeroed gradients behind, cinema_step_prepare zeroes dcoords on a side stream):
+ * the call then skips its own hipMemsetAsync of that buffer. */
+#define CINEMA_BWD_GRADS_CLEARED 2
+#define CINEMA_BWD_DCOORDS_CLEARED 64
 
 int cinema_version(void);
 const char *cinema_last_error(void);
@@ -184,6 +189,26 @@ int cinema_sample_loss_fwd_bwd(const float *out, const float *target, const int6
                                float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
                                void *stream);
 
+/* The same call for a training loop that prepared `sums` beforehand with cinema_step_prepare (typically on a second
+ * stream, beside the forward pass): no memset, no class-weight pre-pass -- sums[0], [1], [3] must be zero and, with
+ * class_w, sums[2] = sum of class_w[label] over the batch (labels do not depend on the network output). */
+int cinema_sample_loss_fwd_bwd_prepared(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                                        const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                                        int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                                        float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                                        void *stream);
+
+/* Per-step clearing for a training loop (build_atlas.py:69-88 does optimizer.zero_grad() + a loss per step), ONE launch:
+ * zeroes dcoords [n_dcoords] fp32 (may be NULL) and sums[0..3]; with class_w it also sets sums[2] to the sum of
+ * class_w[labels[subj*V + voxel]] over the N samples (the normaliser of the weighted cross-entropy, utils.py:86,95).
+ * scratch: 4-byte device scratch of CINEMA_PREPARE_SCRATCH entries, zeroed ONCE by the caller before the first call
+ * (per-workgroup partial sums + the arrival counter the last workgroup resets); calls sharing one scratch must not overlap.
+ * Independent of the forward pass: meant for a second stream. */
+#define CINEMA_PREPARE_SCRATCH 260
+int cinema_step_prepare(float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const int32_t *subj,
+                        const uint8_t *labels, int64_t V, int64_t N, int32_t n_cls, const float *class_w, float *scratch,
+                        void *stream);
+
 /* Dense-inference epilogue (models/inr_decoder.py:50-57): clamp, per-modality min/max over
  * the whole volume (two passes: cinema_infer_minmax then cinema_infer_finish), argmax,
  * softmax, channel concat -> vol [G x (sr_dims + 1 + n_cls)] fp32.
@@ -210,6 +235,9 @@ typedef struct cinema_adamw_group {
 } cinema_adamw_group;
 
 int cinema_adamw_step(const cinema_adamw_group *groups /* host */, int32_t n_groups, void *stream);
+/* Same update; the gradients are zeroed once they have been consumed (optimizer.step() + the next step's
+ * optimizer.zero_grad(), build_atlas.py:82-87, in one pass over the gradient). */
+int cinema_adamw_step_clear(const cinema_adamw_group *groups /* host */, int32_t n_groups, void *stream);
 
 #ifdef __cplusplus
 }

@@ -117,7 +117,7 @@ def _dp_worker(rank, port, out_dir):
         torch.manual_seed(100 + rank)                              # different MLP init per rank: rank 0's must win
         store = SubjectStore.synthetic(2, (20, 20, 20), 155.0 / 20, [155, 155, 155], 2, 10, seed=50 + rank, device=DEV)
         store.shuffle(torch.Generator(device=DEV).manual_seed(7 + rank))
-        tr = HotPathTrainer(_trainer_args(), store, DEV)
+        tr = HotPathTrainer(_trainer_args(), store, DEV, keep_grads=True)
         flat0 = tr.eng.flat.detach().cpu().clone()
         n = 512
         tr.step(0, n)

@@ -98,7 +98,7 @@ def test_nifti_to_trainer_step_matches_oracle(tmp_path):
     assert np.array_equal(store.labels.cpu().numpy(), ov[:, 2].astype(np.uint8))
     _assert_within_one_ulp(store.coords.cpu().numpy(), oc)
     torch.manual_seed(5)
-    tr = HotPathTrainer(args, store, DEV)
+    tr = HotPathTrainer(args, store, DEV, keep_grads=True)
     store.shuffle(torch.Generator(device=DEV).manual_seed(2), group_chunk=900)
     n = 900
     lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()

@@ -102,7 +102,7 @@ def test_trainer_step_matches_oracle(precision, grouped):
     store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700 if grouped else None)
     if grouped:      # every step-sized chunk is sorted by subject -> the sorted K1 backward entry point is taken
         assert bool((store.subj[:700][1:] >= store.subj[:700][:-1]).all()) and bool((store.subj[700:1400][1:] >= store.subj[700:1400][:-1]).all())
-    tr = HotPathTrainer(args, store, DEV)
+    tr = HotPathTrainer(args, store, DEV, keep_grads=True)
     with torch.no_grad():
         tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
     n = 700
@@ -143,6 +143,37 @@ def test_trainer_step_matches_oracle(precision, grouped):
     assert rel_err(tr.latents.detach().cpu().numpy(), ref_p[0].detach().numpy()) < 1e-5
     assert rel_err(tr.tfs.detach().cpu().numpy(), ref_p[1].detach().numpy()) < 1e-5
     assert rel_err(tr.eng.flat.detach().cpu().numpy(), ref_p[2].detach().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_clearing_step_equals_keeping_step(precision):
+    """Default trainer (per-step clearing + class-weight normaliser on the side stream through cinema_step_prepare, K3
+    through the _prepared entry, backward without its memsets, AdamW that zeroes the gradients it consumed) against
+    keep_grads=True (every call clears for itself) over several steps on the same samples: same losses, same
+    parameters (fp32 bias / first-layer gradients go through float atomics: last-bit freedom), gradients left at zero."""
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
+    store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700)
+    trainers = []
+    for keep in (True, False):
+        torch.manual_seed(21)
+        tr = HotPathTrainer(args, store, DEV, keep_grads=keep)
+        with torch.no_grad():
+            tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+        trainers.append(tr)
+    a, b = trainers
+    assert torch.equal(a.eng.flat, b.eng.flat) and torch.equal(a.latents, b.latents)
+    for i in range(4):
+        for tr in (a, b):
+            tr.step(700 * i, 700 * (i + 1))
+        la, lb = a.loss_dict(), b.loss_dict()
+        assert abs(la["total"] - lb["total"]) <= 1e-5 * abs(la["total"]), (i, la, lb)
+        assert float(b.eng.flat_grad.abs().max()) == 0.0 and float(b.lat_grad.abs().max()) == 0.0 and \
+            float(b.tf_grad.abs().max()) == 0.0
+        assert float(a.eng.flat_grad.abs().max()) > 0.0
+    for name, x, y in (("flat", a.eng.flat, b.eng.flat), ("lat", a.latents, b.latents), ("tfs", a.tfs, b.tfs)):
+        assert rel_err(y.detach().cpu().numpy(), x.detach().cpu().numpy()) < 1e-4, name
 
 
 def test_trainer_loss_decreases_over_an_epoch_slice():
