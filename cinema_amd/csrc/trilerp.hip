@@ -80,7 +80,12 @@ __device__ __forceinline__ void shear_mats(const float *e, M3 &sx, M3 &sy, M3 &s
 }
 
 // A = Rz(e0) Rx(e1) Rz(e2) [diag(1+e6..8)] [Sx Sy Sz],  t = e3..5        (utils.py:126-166)
-__device__ __forceinline__ M3 affine_from_embed(const float *e, int dim) {
+// Not inlined on purpose: how the products of a rotation entry get fused (and hence its last bits) depends on the code
+// around an inlined copy, and the kernels that build a subject's affine (k_affine_from_embed, k_trilerp_fwd_sorted) must
+// agree to the bit.  One compiled body, called from both.
+struct Embed12 { float v[12]; };
+__device__ __noinline__ M3 affine_from_embed(Embed12 ev, int dim) {
+  const float *e = ev.v;
   float s1, c1, s2, c2, s3, c3;
   sincosf(e[0], &s1, &c1);
   sincosf(e[1], &s2, &c2);
@@ -103,9 +108,11 @@ __device__ __forceinline__ M3 affine_from_embed(const float *e, int dim) {
 __global__ void k_affine_from_embed(const float *embed, long rows, int dim, float *affine) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  float e[12];
+  Embed12 ev;
+  float (&e)[12] = ev.v;
+#pragma unroll
   for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[r * dim + k] : 0.f;
-  const M3 A = affine_from_embed(e, dim);
+  const M3 A = affine_from_embed(ev, dim);
   float *o = affine + r * 12;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -189,6 +196,12 @@ __global__ void k_node_major(const float *lat, long S, int C, int G, float *shad
   }
 }
 
+// one row of c' = A c + t with the roundings spelled out (left to the compiler, one kernel fuses the products and
+// another one vectorises them into unfused packed multiplies: up to 64 ulp apart where the terms cancel)
+__device__ __forceinline__ float affine_row(float a0, float a1, float a2, float t, float cx, float cy, float cz) {
+  return __builtin_fmaf(a2, cz, __builtin_fmaf(a1, cy, a0 * cx)) + t;
+}
+
 struct Axis {
   int i0, i1;
   float w0, w1;
@@ -250,9 +263,9 @@ __global__ __launch_bounds__(256) void k_trilerp_fwd(TriArgs a) {
     float t0 = cx, t1 = cy, t2 = cz;
     if (a.affine != nullptr) {
       const float *A = a.affine + (a.affine_per_sample ? n : s) * 12;
-      t0 = A[0] * cx + A[1] * cy + A[2] * cz + A[9];
-      t1 = A[3] * cx + A[4] * cy + A[5] * cz + A[10];
-      t2 = A[6] * cx + A[7] * cy + A[8] * cz + A[11];
+      t0 = affine_row(A[0], A[1], A[2], A[9], cx, cy, cz);
+      t1 = affine_row(A[3], A[4], A[5], A[10], cx, cy, cz);
+      t2 = affine_row(A[6], A[7], A[8], A[11], cx, cy, cz);
     }
     if (lane == 0) { a.coords_t[n * 3] = t0; a.coords_t[n * 3 + 1] = t1; a.coords_t[n * 3 + 2] = t2; }
     // coordinate column 0 walks the LAST grid axis (lz), column 1 ly, column 2 lx
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256) void k_trilerp_fwd(TriArgs a) {
     for (int c = lane; c < a.C; c += 64) {
       float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v += w[q] * base[(long)node[q] * a.C + c];
+      for (int q = 0; q < 8; ++q) v = __builtin_fmaf(w[q], base[(long)node[q] * a.C + c], v);   // fused, as in the sorted kernel
       orow[c] = (T)v;
     }
     for (int j = lane; j < a.cond_dims; j += 64) orow[a.C + j] = (T)a.cond[n * a.cond_dims + j];
@@ -619,6 +632,133 @@ __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedA
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// Forward for a batch grouped by subject (any order is computed correctly; a grouped one is fast), table-mode embedding,
+// compile-time grid, C <= 256: a workgroup owns 64 consecutive samples, which in a grouped batch belong to one subject
+// (else the chunk is walked segment by segment).  The subject's table goes from the API layout (C, G) straight into LDS
+// as [node][channel] (no node-major shadow, no separate affine launch on the critical path: a sample's thread builds
+// its subject's affine itself), the 8 corner rows of a sample are LDS reads, a lane owns 4 consecutive channels.
+// Same arithmetic in the same order as k_affine_from_embed + k_trilerp_fwd: bit-identical outputs.
+// ----------------------------------------------------------------------------------------
+struct TriFwdSortedArgs {
+  const float *coords; const int32_t *idx; const float *embed; int tf_dim; const float *latents; const float *cond;
+  long N, Npad, S; int C, cond_dims, LP;
+  float *coords_t; void *lat_out;
+};
+#define TFS_CHUNK 64
+#define TFS_THREADS 256
+#define TFS_CMAX 256
+
+template <typename T, int LX, int LY, int LZ>
+__global__ __launch_bounds__(TFS_THREADS) void k_trilerp_fwd_sorted(TriFwdSortedArgs a) {
+  constexpr int G = LX * LY * LZ;
+  __shared__ __attribute__((aligned(16))) float tab[G * TFS_CMAX];    // [node][channel]
+  __shared__ __attribute__((aligned(16))) float cw[TFS_CHUNK * 8];    // corner weights
+  __shared__ __attribute__((aligned(16))) int cn[TFS_CHUNK * 8];      // corner nodes
+  __shared__ int sid[TFS_CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long base = (long)blockIdx.x * TFS_CHUNK;
+  const int C = a.C;
+  T *out = (T *)a.lat_out;
+  const int nc = (int)(a.N - base < TFS_CHUNK ? (a.N - base > 0 ? a.N - base : 0) : TFS_CHUNK);   // real samples of the chunk
+  auto clamp_s = [&](long sj) { return (int)(sj < 0 ? 0 : (sj >= a.S ? a.S - 1 : sj)); };
+  auto table_request = [&](int s, float (&tv)[G]) {      // thread = channel: G strided reads of the subject's 27 KB block
+    const float *tb = a.latents + ((long)s * C + (tid < C ? tid : 0)) * G;
+#pragma unroll
+    for (int k = 0; k < G; ++k) tv[k] = tb[k];
+  };
+  auto table_commit = [&](const float (&tv)[G]) {
+#pragma unroll
+    for (int k = 0; k < G; ++k) tab[k * TFS_CMAX + tid] = tid < C ? tv[k] : 0.f;
+  };
+  float tv[G];
+  if (nc > 0) table_request(clamp_s(a.idx[base]), tv);
+  if (tid < TFS_CHUNK) {
+    const int t = tid;
+    const long n = base + t;
+    if (t < nc) {
+      const float cx = a.coords[n * 3], cy = a.coords[n * 3 + 1], cz = a.coords[n * 3 + 2];
+      const int s = clamp_s(a.idx[n]);
+      sid[t] = s;
+      float t0 = cx, t1 = cy, t2 = cz;
+      if (a.embed != nullptr) {
+        Embed12 ev;
+        float (&e)[12] = ev.v;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) e[k] = k < a.tf_dim ? a.embed[(long)s * a.tf_dim + k] : 0.f;
+        const M3 A = affine_from_embed(ev, a.tf_dim);
+        t0 = affine_row(A.m[0][0], A.m[0][1], A.m[0][2], e[3], cx, cy, cz);
+        t1 = affine_row(A.m[1][0], A.m[1][1], A.m[1][2], e[4], cx, cy, cz);
+        t2 = affine_row(A.m[2][0], A.m[2][1], A.m[2][2], e[5], cx, cy, cz);
+      }
+      a.coords_t[n * 3] = t0; a.coords_t[n * 3 + 1] = t1; a.coords_t[n * 3 + 2] = t2;
+      const Axis az = axis_nodes(t0, LZ), ay = axis_nodes(t1, LY), ax = axis_nodes(t2, LX);
+      int node[8]; float w[8];
+      corner_setup(ax, ay, az, LY, LZ, node, w);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { cn[t * 8 + q] = node[q]; cw[t * 8 + q] = w[q]; }
+    } else {
+      sid[t] = -1;
+      if (n < a.Npad) { a.coords_t[n * 3] = 0.f; a.coords_t[n * 3 + 1] = 0.f; a.coords_t[n * 3 + 2] = 0.f; }
+    }
+  }
+  // pad rows of the chunk (n >= N): zero
+  for (int t = nc + wave; t < TFS_CHUNK; t += TFS_THREADS / 64) {
+    const long n = base + t;
+    if (n < a.Npad)
+      for (int j = lane; j < a.LP; j += 64) out[n * a.LP + j] = (T)0.f;
+  }
+  if (nc == 0) return;
+  table_commit(tv);
+  __syncthreads();
+  int seg_lo = 0;
+  while (seg_lo < nc) {                                 // one turn per subject present in the chunk (workgroup-uniform)
+    const int s = sid[seg_lo];
+    // the run of samples of s that starts at seg_lo (an unsorted batch just makes short runs)
+    const unsigned long long same = __ballot(lane >= seg_lo && lane < nc && sid[lane] == s) >> seg_lo;
+    const int run = ~same ? __builtin_ctzll(~same) : 64;
+    const int seg_hi = seg_lo + run;
+    if (seg_lo > 0) {
+      __syncthreads();                                  // every wave is done with the previous table
+      table_request(s, tv);
+      table_commit(tv);
+      __syncthreads();
+    }
+    const int ulo = seg_lo > wave * 16 ? seg_lo : wave * 16;
+    const int uhi = seg_hi < wave * 16 + 16 ? seg_hi : wave * 16 + 16;
+#pragma unroll 2
+    for (int t = ulo; t < uhi; ++t) {
+      const long n = base + t;
+      T *orow = out + n * a.LP;
+      if (4 * lane < C) {
+        const int4 nd0 = *reinterpret_cast<const int4 *>(cn + t * 8), nd1 = *reinterpret_cast<const int4 *>(cn + t * 8 + 4);
+        const float4 w0 = *reinterpret_cast<const float4 *>(cw + t * 8), w1 = *reinterpret_cast<const float4 *>(cw + t * 8 + 4);
+        const int nd[8] = {nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, nd1.z, nd1.w};
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 r = *reinterpret_cast<const float4 *>(tab + nd[q] * TFS_CMAX + 4 * lane);
+          v[0] = __builtin_fmaf(w[q], r.x, v[0]); v[1] = __builtin_fmaf(w[q], r.y, v[1]);
+          v[2] = __builtin_fmaf(w[q], r.z, v[2]); v[3] = __builtin_fmaf(w[q], r.w, v[3]);
+        }
+        if constexpr (sizeof(T) == 2) {
+          typedef __attribute__((ext_vector_type(4))) T tx4;
+          tx4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          *reinterpret_cast<tx4 *>(orow + 4 * lane) = o;
+        } else {
+          float4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<float4 *>(orow + 4 * lane) = o;
+        }
+      }
+      for (int j = lane; j < a.cond_dims; j += 64) orow[C + j] = (T)a.cond[n * a.cond_dims + j];
+      for (int j = C + a.cond_dims + lane; j < a.LP; j += 64) orow[j] = (T)0.f;
+    }
+    seg_lo = seg_hi;
+  }
+}
+
 }  // namespace
 
 extern "C" int cinema_affine_from_embedding(const float *embed, int64_t rows, int32_t tf_dim, float *affine, void *stream) {
@@ -655,6 +795,28 @@ extern "C" int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx
   const unsigned grid = (unsigned)std::min<long>((Npad + 3) / 4, 8192);
   if (precision == CINEMA_PREC_BF16) hipLaunchKernelGGL(k_trilerp_fwd<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_trilerp_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                                const float *latents, const float *cond, int64_t N, int64_t Npad, int64_t S,
+                                                int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
+                                                int32_t precision, float *coords_t, void *lat_out, int32_t LP, void *stream) {
+  CINEMA_REQUIRE(coords && idx && latents && coords_t && lat_out, "cinema_affine_trilerp_fwd_sorted: null argument");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_affine_trilerp_fwd_sorted: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
+  CINEMA_REQUIRE(lx == 3 && ly == 3 && lz == 3 && C >= 4 && C <= TFS_CMAX && C % 4 == 0 && LP % 4 == 0,
+                 "cinema_affine_trilerp_fwd_sorted: needs the 3x3x3 grid, C <= %d, C %% 4 == 0 (got %d x %d x %d x %d); use "
+                 "cinema_affine_trilerp_fwd", TFS_CMAX, C, lx, ly, lz);
+  CINEMA_REQUIRE(embed == nullptr || tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+  CINEMA_REQUIRE(cond_dims == 0 || cond != nullptr, "cond_dims %d but cond is null", cond_dims);
+  CINEMA_REQUIRE(LP >= C + cond_dims, "LP %d < C + cond_dims = %d", LP, C + cond_dims);
+  TriFwdSortedArgs a = {coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, LP, coords_t, lat_out};
+  const unsigned grid = (unsigned)((Npad + TFS_CHUNK - 1) / TFS_CHUNK);
+  if (precision == CINEMA_PREC_BF16)
+    hipLaunchKernelGGL((k_trilerp_fwd_sorted<bf16_t, 3, 3, 3>), dim3(grid), dim3(TFS_THREADS), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_trilerp_fwd_sorted<float, 3, 3, 3>), dim3(grid), dim3(TFS_THREADS), 0, (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -217,6 +217,38 @@ def k1_forward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: to
           "cinema_affine_trilerp_fwd")
 
 
+def k1_sorted_eligible(latents_shape, LP: int) -> bool:
+    """Shapes the grouped-batch forward kernel takes (cinema_affine_trilerp_fwd_sorted)."""
+    _, Cc, lx, ly, lz = latents_shape
+    return (lx, ly, lz) == (3, 3, 3) and 4 <= Cc <= 256 and Cc % 4 == 0 and LP % 4 == 0
+
+
+def k1_forward_sorted(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
+                      cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
+    """k1_forward for a batch grouped by subject with a per-subject embedding table: one launch, reads the latent
+    table in its API layout (no shadow, no affine table).  Bit-identical outputs."""
+    lib, d, ws = eng.lib, eng.desc, eng.ws
+    S, Cc, lx, ly, lz = latents.shape
+    cond_dims = 0 if cond is None else cond.shape[1]
+    if Cc + cond_dims != d.lat:
+        raise ValueError(f"latent channels {Cc} + condition dims {cond_dims} != lat_size {d.lat} of the SIREN")
+    npad = round_up(n, ROW_ALIGN)
+    check(lib.cinema_affine_trilerp_fwd_sorted(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
+                                               ptr(latents), ptr(cond) if cond_dims else None, n, npad, S, Cc, lx, ly, lz,
+                                               cond_dims, d.precision, ptr(ws.coords_t), ptr(ws.lat), d.LP, eng.stream()),
+          "cinema_affine_trilerp_fwd_sorted")
+
+
+def k1_shadow(eng: SirenEngine, st: TrilerpState, latents: torch.Tensor):
+    """Node-major shadow of the latent table for the K1 backward (on the current stream)."""
+    S, Cc = latents.shape[0], latents.shape[1]
+    G = latents.shape[2] * latents.shape[3] * latents.shape[4]
+    if st.shadow is None or st.shadow.numel() != S * G * Cc:
+        st.shadow = torch.empty(S, G, Cc, device=eng.device, dtype=torch.float32)
+    check(eng.lib.cinema_latent_to_node_major(ptr(latents), S, Cc, G, ptr(st.shadow), eng.stream()),
+          "cinema_latent_to_node_major")
+
+
 def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
                 cond_dims: int, tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int,
                 want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None,

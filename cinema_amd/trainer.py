@@ -150,6 +150,7 @@ class HotPathTrainer:
         # Together: four fills and the class-weight pre-pass (25 us) leave the critical path of a step.
         self.side = torch.cuda.Stream(device=self.device)
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
+        self.ev_pack, self.ev_prep = torch.cuda.Event(), torch.cuda.Event()
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -171,13 +172,23 @@ class HotPathTrainer:
         main, side = torch.cuda.current_stream(self.device), self.side
         side.wait_stream(main)                      # the previous step's optimiser wrote the parameters
         use_cw = self.class_w is not None and self.seg_weight > 0
+        grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
+        fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
         with torch.cuda.stream(side):
+            eng.pack()                                            # the forward waits for this ...
+            self.ev_pack.record(side)
+            if fast_k1:
+                E.k1_shadow(eng, self.k1, self.latents.data)      # ... only the backward reads the shadow ...
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
-                           self.prep_scratch)
-            eng.pack()
-        E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
-        main.wait_stream(side)                      # ONE join: every cross-stream wait costs ~6 us of idle queue
+                           self.prep_scratch)                     # ... and only the loss kernel the cleared sums
+            self.ev_prep.record(side)
+        if fast_k1:
+            E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
+        else:
+            E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
+        main.wait_event(self.ev_pack)
         eng.forward(n)
+        main.wait_event(self.ev_prep)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
                       labels=st.labels, voxels_per_subject=st.V, prepared=True)
@@ -186,7 +197,6 @@ class HotPathTrainer:
         if self.train_mlp and self.world > 1:
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
         want_tf = self.tfs.requires_grad
-        grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
                                     want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,

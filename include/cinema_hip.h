@@ -146,6 +146,16 @@ int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx, const flo
                               int32_t cond_dims, int32_t precision, float *coords_t, void *lat_out, int32_t LP,
                               void *stream);
 
+/* The same forward for a training loop whose batches are grouped by subject and whose embeddings are a per-subject
+ * table: embed [S x tf_dim] (or NULL) and the latent table in its API layout (S, C, G) go in directly -- no affine
+ * table, no node-major shadow.  64-sample chunks keep their subject's table in LDS; any idx order is computed
+ * correctly, only a grouped one is fast.  3x3x3 grid, C <= 256, C % 4 == 0, LP % 4 == 0 (else: error, use the call
+ * above).  Outputs are bit-identical to cinema_affine_from_embedding + cinema_affine_trilerp_fwd. */
+int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                     const float *latents, const float *cond, int64_t N, int64_t Npad, int64_t S,
+                                     int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t precision,
+                                     float *coords_t, void *lat_out, int32_t LP, void *stream);
+
 /* Backward of the above:
  *   dlat [Npad x LP] fp32, dcoords_t [Npad x 3] fp32 (gradient reaching the registered
  *   coordinates through the SIREN's first layer; the interpolation term is added here),

@@ -192,3 +192,41 @@ def test_trainer_loss_decreases_over_an_epoch_slice():
             first = tr.loss_dict()["total"]
     last = tr.loss_dict()["total"]
     assert np.isfinite(last) and last < 0.8 * first, (first, last)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("tf_dim,cond_dims,order", [(6, 0, "grouped"), (12, 2, "grouped"), (9, 0, "shuffled")])
+def test_sorted_k1_forward_is_bit_identical(precision, tf_dim, cond_dims, order):
+    """cinema_affine_trilerp_fwd_sorted (table in LDS, API-layout latents, affine built in the kernel) against
+    cinema_affine_from_embedding + cinema_latent_to_node_major + cinema_affine_trilerp_fwd: same bits in coords_t and
+    lat (pad rows and pad columns included), for grouped and for arbitrary sample order, ragged N."""
+    from cinema_amd import _lib, engine as E
+    S, Cc, n = 7, 48, 1000 + 37
+    lat_size = Cc + cond_dims
+    d = E.make_desc(3, lat_size, 12, 128, 4, [1, 3], 30, 30, _lib.PREC_BF16 if precision == "bf16" else _lib.PREC_F32)
+    eng = E.SirenEngine(d, DEV)
+    g = torch.Generator().manual_seed(3)
+    latents = (torch.randn(S, Cc, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    tfs = ((torch.rand(S, tf_dim, generator=g) - 0.5) * 0.2).to(DEV)
+    coords = (torch.rand(n, 3, generator=g) * 2.4 - 1.2).to(DEV)          # some outside [-1, 1]: border clamp
+    idx = torch.randint(0, S - 1, (n,), generator=g, dtype=torch.int32)   # subject S-1 has no samples
+    if order == "grouped":
+        idx = idx.sort().values
+    idx = idx.to(DEV)
+    cond = torch.randn(n, cond_dims, generator=g).to(DEV) if cond_dims else None
+    assert E.k1_sorted_eligible(tuple(latents.shape), d.LP)
+    ws = eng.workspace(n)
+    st = E.TrilerpState()
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
+    E.k1_forward(eng, st, coords, idx, latents, cond, tfs, False, n)
+    ref_c, ref_l = ws.coords_t.clone(), ws.lat.clone()
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
+    E.k1_forward_sorted(eng, coords, idx, latents, cond, tfs, n)
+    torch.cuda.synchronize()
+    npad = E.round_up(n, 128)
+    assert torch.equal(ws.coords_t[:npad].view(torch.int32), ref_c[:npad].view(torch.int32))
+    bits = torch.int16 if precision == "bf16" else torch.int32
+    assert torch.equal(ws.lat[:npad].view(bits), ref_l[:npad].view(bits))
+    # no embedding table at all: coordinates pass through
+    E.k1_forward_sorted(eng, coords, idx, latents, cond, None, n)
+    assert torch.equal(ws.coords_t[:n], coords)
