@@ -50,6 +50,7 @@ SIGNATURES = {
     "cinema_last_error": [],
     "cinema_siren_plan": [C.POINTER(SirenDesc)],
     "cinema_siren_pack": [C.POINTER(SirenDesc), _P, _P, _P],
+    "cinema_siren_pack_part": [C.POINTER(SirenDesc), _P, _P, _I32, _P],
     "cinema_siren_forward": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I64, _I64, _P, _P, _P],
     "cinema_siren_backward": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I32, _P],
     "cinema_affine_from_embedding": [_P, _I64, _I32, _P, _P],

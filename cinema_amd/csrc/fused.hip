@@ -88,12 +88,23 @@ struct PackSideArgs {
   int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;
   unsigned mod_mask; int n_layers, H, HP, in_dim;
   long off_wf; int out_dim, lat;
+  bf16_t *dst_wf; int LP;      // final_linear padded to [16][HP + LP] bf16 (read by the forward's last layer)
 };
 
 __global__ void k_pack_side(PackSideArgs a) {
   const int total = a.lb_total + 4 * a.HP + 16 * a.HP;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  const int total_wf = 16 * (a.HP + a.LP);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + total_wf; e += gridDim.x * blockDim.x) {
     float x = 0.f;
+    if (e >= total) {
+      const int q = e - total, o = q / (a.HP + a.LP), col = q - o * (a.HP + a.LP);
+      if (o < a.out_dim) {
+        if (col < a.HP) { if (col < a.H) x = a.params[a.off_wf + (long)o * (a.H + a.lat) + col]; }
+        else if (col - a.HP < a.lat) x = a.params[a.off_wf + (long)o * (a.H + a.lat) + a.H + (col - a.HP)];
+      }
+      a.dst_wf[q] = (bf16_t)x;
+      continue;
+    }
     if (e >= a.lb_total + 4 * a.HP) {          // final_linear.weight[:, :H] as [16][HP] (backward, top of the chain)
       const int q = e - a.lb_total - 4 * a.HP, o = q / a.HP, f = q - o * a.HP;
       if (o < a.out_dim && f < a.H) x = a.params[a.off_wf + (long)o * (a.H + a.lat) + f];
@@ -681,7 +692,8 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
   b.off_w0 = d->off_w[0];
   b.mod_mask = d->modulated_mask; b.n_layers = d->n_layers; b.H = d->hidden; b.HP = d->HP; b.in_dim = d->in_dim;
   b.off_wf = d->off_wf; b.out_dim = d->out_dim; b.lat = d->lat;
-  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 20 * d->HP + 255) / 256), dim3(256), 0, s, b);
+  b.dst_wf = (bf16_t *)packed + d->pk_wf; b.LP = d->LP;
+  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 20 * d->HP + 16 * (d->HP + d->LP) + 255) / 256), dim3(256), 0, s, b);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -914,7 +914,9 @@ static int fused_mode(const cinema_siren_desc *d) {   // 0 = layered kernels, 64
 }
 
 template <typename T>
-static int pack_impl(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
+static int pack_impl(const cinema_siren_desc *d, const float *params, void *packed, int part, hipStream_t s) {
+  // part bit 0: what the forward reads; bit 1: what only the backward reads (fused mode: the transposed linear_lats
+  // copies of the d-latent GEMM; the layer-by-layer mode packs everything under bit 0)
   PackArgs a;
   int nj = 0;
   const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP;
@@ -934,6 +936,10 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
   };
   // W, W^T and the row-major linear_lats copies are only read by the layer-by-layer kernels
   const bool fwd_layered = fused_mode(d) == 0;
+  if (!fwd_layered && (part & 1))
+    if (int rc = fused_pack(d, params, packed, s)) return rc;     // weight streams, side block, padded final_linear
+  if (!fwd_layered && !(part & 2)) return 0;
+  if (fwd_layered && !(part & 1)) return 0;
   for (int i = 0; i < d->n_layers; ++i) {
     if (i > 0) {
       if (fwd_layered) {   // the fused chain kernels read the weight streams instead
@@ -951,21 +957,27 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
       if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
     }
   }
-  // final linear: one job per (output row, x | lat part), padded to 16 rows
-  for (int o = 0; o < 16; ++o) {
+  // final linear: one job per (output row, x | lat part), padded to 16 rows (fused mode: k_pack_side writes it)
+  for (int o = 0; o < 16 && fwd_layered; ++o) {
     const bool live = o < d->out_dim;
     const float *row = params + d->off_wf + (size_t)(live ? o : 0) * (H + L);
     if (int rc = add(row, d->pk_wf + (long)o * (HP + LP), live ? 1 : 0, H, H + L, 1, HP, 0)) return rc;
     if (int rc = add(row + H, d->pk_wf + (long)o * (HP + LP) + HP, live ? 1 : 0, L, H + L, 1, LP, 0)) return rc;
   }
-  if (int rc = flush()) return rc;
-  return fwd_layered ? 0 : fused_pack(d, params, packed, s);
+  return flush();
+}
+
+extern "C" int cinema_siren_pack_part(const cinema_siren_desc *d, const float *params, void *packed, int32_t part,
+                                      void *stream) {
+  CINEMA_REQUIRE(d && params && packed, "cinema_siren_pack: null argument");
+  CINEMA_REQUIRE(part >= 1 && part <= 3, "cinema_siren_pack_part: part must be 1 (forward), 2 (backward-only) or 3 (both)");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16 ? pack_impl<bf16_t>(d, params, packed, part, s)
+                                          : pack_impl<float>(d, params, packed, part, s);
 }
 
 extern "C" int cinema_siren_pack(const cinema_siren_desc *d, const float *params, void *packed, void *stream) {
-  CINEMA_REQUIRE(d && params && packed, "cinema_siren_pack: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  return d->precision == CINEMA_PREC_BF16 ? pack_impl<bf16_t>(d, params, packed, s) : pack_impl<float>(d, params, packed, s);
+  return cinema_siren_pack_part(d, params, packed, 3, stream);
 }
 
 template <typename T, bool MOD, bool SMALLK>

@@ -137,9 +137,10 @@ class SirenEngine:
         return self.ws
 
     # -- steps ------------------------------------------------------------------------
-    def pack(self):
-        """Refresh the packed compute copies from the flat fp32 parameters (one launch)."""
-        check(self.lib.cinema_siren_pack(C.byref(self.desc), ptr(self.flat), ptr(self.packed), self.stream()),
+    def pack(self, part: int = 3):
+        """Refresh the packed compute copies from the flat fp32 parameters.
+        part 1: what the forward reads, 2: what only the backward reads, 3: both."""
+        check(self.lib.cinema_siren_pack_part(C.byref(self.desc), ptr(self.flat), ptr(self.packed), part, self.stream()),
               "cinema_siren_pack")
 
     def can_skip_saved(self) -> bool:

@@ -175,10 +175,11 @@ class HotPathTrainer:
         grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
         with torch.cuda.stream(side):
-            eng.pack()                                            # the forward waits for this ...
+            eng.pack(1)                                           # the forward waits for this ...
             self.ev_pack.record(side)
+            eng.pack(2)                                           # ... the rest is read by the backward only:
             if fast_k1:
-                E.k1_shadow(eng, self.k1, self.latents.data)      # ... only the backward reads the shadow ...
+                E.k1_shadow(eng, self.k1, self.latents.data)      # transposed linear_lats copies, node-major shadow ...
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
                            self.prep_scratch)                     # ... and only the loss kernel the cleared sums
             self.ev_prep.record(side)

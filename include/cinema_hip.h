@@ -101,6 +101,10 @@ int cinema_siren_plan(cinema_siren_desc *d /* host */);
  * launch.  Replaces nothing in the reference: it is the layout change that lets
  * siren.py:30-35 run as MFMA GEMMs. */
 int cinema_siren_pack(const cinema_siren_desc *d /* host */, const float *params, void *packed, void *stream);
+/* The same in two parts for a training loop that packs beside other work: part 1 = the copies the forward reads,
+ * part 2 = the copies only the backward reads (the forward can start after part 1), 3 = both. */
+int cinema_siren_pack_part(const cinema_siren_desc *d /* host */, const float *params, void *packed, int32_t part,
+                           void *stream);
 
 /* Siren.forward (models/siren.py:59-61) incl. every SineLayer.forward (siren.py:26-36):
  *   out[n, :] = final_linear(cat(x_L, lat)),  x_{l+1} = sin(w z) | sin(w z s + t).
