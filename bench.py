@@ -81,6 +81,26 @@ def cpu_baseline(args, n_samples, n_subjects, budget_s=25.0):
                       f"N={n_samples}, S={n_subjects}, fp32, torch CPU ops, median"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
+    (profiles/r01f_pmc_fetch.txt, _write.txt: separate --pmc runs of this script, tools/profile_round.sh).  Counters
+    are in KiB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    gfx950 (128-B requests tallied at 64 B), WRITE_SIZE is exact.  A live run cannot collect counters on itself, so
+    this is the profile of the same command, not of this process; (None, None) when the files are absent."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    vals = {}
+    for key, name in (("FETCH_SIZE", "r01f_pmc_fetch.txt"), ("WRITE_SIZE", "r01f_pmc_write.txt")):
+        path = os.path.join(here, "profiles", name)
+        if not os.path.exists(path):
+            return None, None
+        for line in open(path):
+            if line.startswith(kernel) and key + "=" in line:
+                vals[key] = float(line.split(key + "=")[1].split()[0])
+    if len(vals) != 2:
+        return None, None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01f_pmc_fetch.txt (x2) + profiles/r01f_pmc_write.txt"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,9 +205,10 @@ def main():
         ach = n * bytes_per_sample / (ms * 1e-3) / 1e9
         kname = ("k_fused_bwd (backward chain of the SIREN stack, one launch)" if opt.precision == "bf16"
                  else "k_layer_bwd x layers (backward chain, fp32 layer-by-layer kernels)")
+        traffic, traffic_src = pmc_traffic("k_fused_bwd") if opt.precision == "bf16" and n == 25000 else (None, None)
         roofline = {"kernel": kname, "bound": "hbm",
-                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "avg_launch_ms": ms, "bytes_per_launch": n * bytes_per_sample}
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_src, "avg_launch_ms": ms, "bytes_per_launch": n * bytes_per_sample}
         peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ms_dw = time_phase(_lib.BWD_PHASE_DW)
         macs = n * (5 * d.hidden * d.hidden + 3 * 2 * d.hidden * d.lat)           # dW of 5 linear + 3 linear_lats
