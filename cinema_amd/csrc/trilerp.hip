@@ -484,16 +484,16 @@ __global__ __launch_bounds__(1024) void k_group_small(const int32_t *idx, long N
 
 // Table mode, one block per subject: sum d c^T and d over the subject's samples (embed_grad is linear in them), then
 // ONE evaluation of the embedding gradient per subject.  Replaces the per-sample rows + their per-subject reduction.
-__global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, const int32_t *perm, const float *coords,
-                                                      const float *dct, const float *embed, int dim, float *dembed) {
-  __shared__ float red[4][12];
-  const long s = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// (any workgroup size up to 1024: the body also runs as one extra blockIdx.y slice of k_lat_reduce_dense)
+__device__ __forceinline__ void tf_table_bwd_body(const int32_t *offsets, const int32_t *perm, const float *coords,
+                                                  const float *dct, const float *embed, int dim, float *dembed, long s) {
+  __shared__ float red[16][12];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (blockDim.x + 63) >> 6;
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
 #pragma unroll 2
-  for (int p = offsets[s] + tid; p < offsets[s + 1]; p += 256) {
+  for (int p = offsets[s] + tid; p < offsets[s + 1]; p += blockDim.x) {
     const long n = perm != nullptr ? perm[p] : p;
     const float c[3] = {coords[n * 3], coords[n * 3 + 1], coords[n * 3 + 2]};
     const float d[3] = {dct[n * 3], dct[n * 3 + 1], dct[n * 3 + 2]};
@@ -513,12 +513,17 @@ __global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, co
   __syncthreads();
   if (tid == 0) {
     M3 G;
-    float d[3], e[12], g[12];
+    float d[3], e[12], g[12], t[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      t[k] = 0.f;
+      for (int w = 0; w < nwave; ++w) t[k] += red[w][k];
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) G.m[i][j] = red[0][i * 3 + j] + red[1][i * 3 + j] + red[2][i * 3 + j] + red[3][i * 3 + j];
-      d[i] = red[0][9 + i] + red[1][9 + i] + red[2][9 + i] + red[3][9 + i];
+      for (int j = 0; j < 3; ++j) G.m[i][j] = t[i * 3 + j];
+      d[i] = t[9 + i];
     }
     for (int k = 0; k < 12; ++k) e[k] = k < dim ? embed[s * dim + k] : 0.f;
     embed_grad(e, dim, G, d, g);
@@ -526,11 +531,18 @@ __global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, co
   }
 }
 
+__global__ __launch_bounds__(256) void k_tf_table_bwd(const int32_t *offsets, const int32_t *perm, const float *coords,
+                                                      const float *dct, const float *embed, int dim, float *dembed) {
+  tf_table_bwd_body(offsets, perm, coords, dct, embed, dim, dembed, blockIdx.x);
+}
+
 
 // d latents: one workgroup per (subject, 64-channel slice); the subject's samples are summed in LDS
 struct LatRedArgs {
   const int32_t *offsets; const int32_t *perm; const float *coords_t; const float *dlat;
   int C, lx, ly, lz, LP; float *dlatents;
+  // table-mode embedding gradient riding along as slice blockIdx.y == gridDim.y - 1 of k_lat_reduce_dense (tf_dembed != NULL)
+  const float *tf_coords; const float *tf_dct; const float *tf_embed; int tf_dim; float *tf_dembed;
 };
 __global__ __launch_bounds__(256) void k_lat_reduce(LatRedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -584,6 +596,10 @@ __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedA
   __shared__ float part[LATRED_WAVES][G][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long s = blockIdx.x;
+  if (a.tf_dembed != nullptr && blockIdx.y == gridDim.y - 1) {        // workgroup-uniform
+    tf_table_bwd_body(a.offsets, a.perm, a.tf_coords, a.tf_dct, a.tf_embed, a.tf_dim, a.tf_dembed, s);
+    return;
+  }
   const int c0 = blockIdx.y * 64, c = c0 + lane;
   const int beg = a.offsets[s], end = a.offsets[s + 1];
   float acc[G];
@@ -857,9 +873,13 @@ static int trilerp_bwd_impl(bool sorted, const float *coords, const int32_t *idx
     }
     CINEMA_CHECK_HIP(hipGetLastError());
   }
+  const bool dense_grid = (lx == ly && ly == lz && lx >= 1 && lx <= 3);
+  const bool tf_rides = table_tf && dlatents != nullptr && dense_grid;    // one launch: extra slice of k_lat_reduce_dense
   if (dembed != nullptr) {
     CINEMA_REQUIRE(embed != nullptr, "dembed requested but embed is null");
     CINEMA_REQUIRE(tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+  }
+  if (dembed != nullptr && !tf_rides) {
     if (table_tf)
       hipLaunchKernelGGL(k_tf_table_bwd, dim3((unsigned)S), dim3(256), 0, s, offsets, perm, coords, dcoords_t, embed, tf_dim,
                          dembed);
@@ -872,8 +892,9 @@ static int trilerp_bwd_impl(bool sorted, const float *coords, const int32_t *idx
     const int smem = 4 * G * 64 * (int)sizeof(float);
     CINEMA_REQUIRE(smem <= 64 * 1024, "latent grid of %d nodes too large for the LDS reduction (max 64)", G);
     CINEMA_REQUIRE(S <= 0x7fffffff && (C + 63) / 64 <= 65535, "grid too large");
-    LatRedArgs a = {offsets, perm, coords_t, dlat, C, lx, ly, lz, LP, dlatents};
-    const dim3 grid((unsigned)S, (C + 63) / 64);
+    LatRedArgs a = {offsets, perm, coords_t, dlat, C, lx, ly, lz, LP, dlatents, coords, dcoords_t, embed, tf_dim,
+                    tf_rides ? dembed : nullptr};
+    const dim3 grid((unsigned)S, (C + 63) / 64 + (tf_rides ? 1 : 0));
     if (lx == 3 && ly == 3 && lz == 3) hipLaunchKernelGGL((k_lat_reduce_dense<3, 3, 3>), grid, dim3(128 * LATRED_WAVES), 0, s, a);
     else if (lx == 1 && ly == 1 && lz == 1) hipLaunchKernelGGL((k_lat_reduce_dense<1, 1, 1>), grid, dim3(128 * LATRED_WAVES), 0, s, a);
     else if (lx == 2 && ly == 2 && lz == 2) hipLaunchKernelGGL((k_lat_reduce_dense<2, 2, 2>), grid, dim3(128 * LATRED_WAVES), 0, s, a);

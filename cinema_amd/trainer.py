@@ -148,7 +148,10 @@ class HotPathTrainer:
         # The same stream carries the per-step clearing (registered-coordinate gradient, loss sums) and the class-weight
         # normaliser of the batch, none of which depends on the forward; the optimiser leaves the gradients zeroed.
         # Together: four fills and the class-weight pre-pass (25 us) leave the critical path of a step.
-        self.side = torch.cuda.Stream(device=self.device)
+        # One process of several (world > 1) keeps everything on ONE stream for now: the collective library brings its
+        # own streams, the two-event choreography above has not run next to RCCL on a real node yet, and the 35 us it
+        # saves per step are not worth risking a stalled job in the round's only multi-GPU run.
+        self.side = torch.cuda.Stream(device=self.device) if self.world == 1 else None
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_pack, self.ev_prep = torch.cuda.Event(), torch.cuda.Event()
         self.n_last = 0
@@ -169,27 +172,41 @@ class HotPathTrainer:
             table = self.cond_param.data if self.cond_param is not None else st.conditions
             cond = table[subj.long()].contiguous()
         tfs = self.tfs.data
-        main, side = torch.cuda.current_stream(self.device), self.side
-        side.wait_stream(main)                      # the previous step's optimiser wrote the parameters
+        main = torch.cuda.current_stream(self.device)
         use_cw = self.class_w is not None and self.seg_weight > 0
         grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
-        with torch.cuda.stream(side):
-            eng.pack(1)                                           # the forward waits for this ...
-            self.ev_pack.record(side)
-            eng.pack(2)                                           # ... the rest is read by the backward only:
+
+        def k1_fwd():
             if fast_k1:
-                E.k1_shadow(eng, self.k1, self.latents.data)      # transposed linear_lats copies, node-major shadow ...
+                E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
+            else:
+                E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
+
+        def backward_only_prep():
+            eng.pack(2)                                           # transposed linear_lats copies,
+            if fast_k1:
+                E.k1_shadow(eng, self.k1, self.latents.data)      # node-major shadow (only the K1 backward reads it),
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
-                           self.prep_scratch)                     # ... and only the loss kernel the cleared sums
-            self.ev_prep.record(side)
-        if fast_k1:
-            E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
+                           self.prep_scratch)                     # cleared sums / dcoords + class-weight normaliser
+
+        if self.side is not None:
+            side = self.side
+            side.wait_stream(main)                  # the previous step's optimiser wrote the parameters
+            with torch.cuda.stream(side):
+                eng.pack(1)                         # the forward waits for this ...
+                self.ev_pack.record(side)
+                backward_only_prep()                # ... the loss kernel for the rest
+                self.ev_prep.record(side)
+            k1_fwd()
+            main.wait_event(self.ev_pack)
         else:
-            E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
-        main.wait_event(self.ev_pack)
+            eng.pack(1)
+            k1_fwd()
+            backward_only_prep()
         eng.forward(n)
-        main.wait_event(self.ev_prep)
+        if self.side is not None:
+            main.wait_event(self.ev_prep)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
                       labels=st.labels, voxels_per_subject=st.V, prepared=True)

@@ -122,8 +122,9 @@ def _dp_worker(rank, port, out_dir):
         n = 512
         tr.step(0, n)
         torch.cuda.synchronize()
-        torch.save({"flat0": flat0, "flat1": tr.eng.flat.detach().cpu(), "grad": tr.eng.flat_grad.detach().cpu(),
-                    "loss": tr.loss_dict()["total"]}, os.path.join(out_dir, f"rank{rank}.pt"))
+        out = {"flat0": flat0, "flat1": tr.eng.flat.detach().cpu(), "grad": tr.eng.flat_grad.detach().cpu(),
+               "loss": tr.loss_dict()["total"]}
+        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 

@@ -145,13 +145,21 @@ def test_trainer_step_matches_oracle(precision, grouped):
     assert rel_err(tr.eng.flat.detach().cpu().numpy(), ref_p[2].detach().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_clearing_step_equals_keeping_step(precision):
+@pytest.mark.parametrize("precision,as_rank_of_two", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_clearing_step_equals_keeping_step(precision, as_rank_of_two, monkeypatch):
     """Default trainer (per-step clearing + class-weight normaliser on the side stream through cinema_step_prepare, K3
     through the _prepared entry, backward without its memsets, AdamW that zeroes the gradients it consumed) against
     keep_grads=True (every call clears for itself) over several steps on the same samples: same losses, same
     parameters (fp32 bias / first-layer gradients go through float atomics: last-bit freedom), gradients left at zero."""
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    from cinema_amd import parallel as par
+    if as_rank_of_two:
+        # the code path of one rank of several in ONE process (two ranks sharing this box's single GPU stall for seconds
+        # per collective): separate optimiser launch for the MLP after the all-reduce, everything on one stream.  The
+        # collective itself is replaced by the identity (a replica whose peer computed the same gradient).
+        monkeypatch.setattr(par, "world_info", lambda pg=None: (0, 2))
+        monkeypatch.setattr(par, "broadcast_", lambda t, src=0, pg=None: t)
+        monkeypatch.setattr(par, "allreduce_mean_", lambda g, pg=None, async_op=False: None)
     args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
     store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
     store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700)
@@ -164,6 +172,7 @@ def test_clearing_step_equals_keeping_step(precision):
         trainers.append(tr)
     a, b = trainers
     assert torch.equal(a.eng.flat, b.eng.flat) and torch.equal(a.latents, b.latents)
+    assert (b.side is None and b.opt_mlp is not None) if as_rank_of_two else (b.side is not None and b.opt_mlp is None)
     for i in range(4):
         for tr in (a, b):
             tr.step(700 * i, 700 * (i + 1))
