@@ -153,7 +153,7 @@ class HotPathTrainer:
         # saves per step are not worth risking a stalled job in the round's only multi-GPU run.
         self.side = torch.cuda.Stream(device=self.device) if self.world == 1 else None
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
-        self.ev_pack, self.ev_prep = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_prep = torch.cuda.Event()
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -194,12 +194,10 @@ class HotPathTrainer:
             side = self.side
             side.wait_stream(main)                  # the previous step's optimiser wrote the parameters
             with torch.cuda.stream(side):
-                eng.pack(1)                         # the forward waits for this ...
-                self.ev_pack.record(side)
-                backward_only_prep()                # ... the loss kernel for the rest
+                backward_only_prep()                # nothing the forward reads: beside it, joined before the loss kernel
                 self.ev_prep.record(side)
-            k1_fwd()
-            main.wait_event(self.ev_pack)
+            eng.pack(1)                             # what the forward reads stays on this stream: a cross-stream wait
+            k1_fwd()                                # costs more idle queue (6-10 us) than the overlap with K1 would save
         else:
             eng.pack(1)
             k1_fwd()
