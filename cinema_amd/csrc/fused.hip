@@ -10,6 +10,7 @@
 #include "fused.h"
 #include "gemm_engine.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -148,11 +149,11 @@ __device__ __forceinline__ void ring_init(WRing &r, const char *stream, unsigned
 #define FUSED_STEP(SLOT, KSTEP)                                                                              \
   {                                                                                                          \
     const int off_ = ((((KSTEP) << 2) + gk) ^ i) << 4;                                                       \
-    bf16x8 b_[4];                                                                                            \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                         \
+    bf16x8 b_[NST];                                                                                          \
+    _Pragma("unroll") for (int st = 0; st < NST; ++st)                                                       \
       b_[st] = *(const LDS_AS bf16x8 *)(tile + rowoff + st * 16 * rowbytes + off_);                          \
     _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                         \
-      _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                       \
+      _Pragma("unroll") for (int st = 0; st < NST; ++st)                                                     \
         acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
     ring_fetch(r.s[SLOT], r.wp, lane16);                                                                     \
     r.wp += 4096;                                                                                            \
@@ -163,7 +164,8 @@ __device__ __forceinline__ void ring_init(WRing &r, const char *stream, unsigned
 // is padded to a multiple of FUSED_RING steps (zero weights against zeroed LDS columns), so the ring phase is always
 // 0 at a segment boundary and the slots are addressed statically (a run-time slot index makes hipcc keep every slot
 // twice and spill; with static slots its own counted vmcnt(15..12) waits come out exact).
-__device__ __forceinline__ void run_seg(f32x4 (&acc)[4][4], WRing &r, const lds_char *tile, int rowbytes, int nsteps,
+template <int NST>
+__device__ __forceinline__ void run_seg(f32x4 (&acc)[4][NST], WRing &r, const lds_char *tile, int rowbytes, int nsteps,
                                         int i, int gk, unsigned lane16) {
   const int rowoff = i * rowbytes;
   for (int k = 0; k < nsteps; k += 4) {
@@ -172,11 +174,12 @@ __device__ __forceinline__ void run_seg(f32x4 (&acc)[4][4], WRing &r, const lds_
 }
 static_assert(FUSED_RING == 4, "run_seg is written for a 4-step ring");
 
-__device__ __forceinline__ void fill_acc(f32x4 (&acc)[4][4], const f32x4 (&v)[4]) {
+template <int NST>
+__device__ __forceinline__ void fill_acc(f32x4 (&acc)[4][NST], const f32x4 (&v)[4]) {
 #pragma unroll
   for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-    for (int st = 0; st < 4; ++st) acc[ft][st] = v[ft];
+    for (int st = 0; st < NST; ++st) acc[ft][st] = v[ft];
 }
 
 // v[q] = bias[off + fb + 4q .. +3] from the LDS copy of the biases (each vector zero-padded to HP)
@@ -203,6 +206,7 @@ __device__ __forceinline__ void pack16(const float (&v)[16], bf16x8 &lo, bf16x8 
 // fused forward
 // ----------------------------------------------------------------------------------------
 struct FusedFwdArgs {
+  int g4;                            // workgroups [0, g4) own 64 samples, the rest 48 (fused_launch_plan)
   const bf16_t *stream; long slab_elems;
   const float *params;
   long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0;
@@ -218,7 +222,10 @@ struct FusedFwdArgs {
   int trace_block, trace_wave;
 };
 
-__global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
+// NST = sample tiles of 16 per workgroup: 4 (64 samples) or 3 (48: the second, shorter round of a batch that fills the
+// chip between one and two times -- its workgroups pay the same weight stream but three quarters of the epilogues)
+template <int NST>
+__device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long n0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *xs = (lds_char *)smem;
   lds_char *ls = xs + FUSED_TS * a.xrow;
@@ -226,7 +233,6 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
   const int i = lane & 15, g = lane >> 4, gk = g;
-  const long n0 = (long)blockIdx.x * FUSED_TS;
   const int slab = wave;
   const bool active = slab * 64 < a.HP;
   const unsigned fb = slab * 64 + 16 * g;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
     const int cpr = a.lrow >> 4, cdat = a.LP >> 3;
     const char *lt = (const char *)(a.lat + n0 * a.LP);
     const u32x4 z4 = {0u, 0u, 0u, 0u};
-    for (int q = tid; q < FUSED_TS * cpr; q += 512) {
+    for (int q = tid; q < NST * 16 * cpr; q += 512) {
       const int row = q / cpr, c = q - row * cpr;
       u32x4 v = z4;
       if (c < cdat) v = *reinterpret_cast<const u32x4 *>(lt + (unsigned)(row * a.LP + c * 8) * 2u);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
     // biases + first-layer weights: one coalesced copy of the block k_pack_side prepared
     const int nb4 = (a.lb_total + 4 * a.HP) / 4;
     for (int q = tid; q < nb4; q += 512) *(LDS_AS f32x4 *)(bs + q * 16) = *reinterpret_cast<const f32x4 *>(a.side + q * 4);
-    if (tid < FUSED_TS) {
+    if (tid < NST * 16) {
       const float *cp = a.coords_t + (n0 + tid) * a.in_dim;
       f32x4 c = {cp[0], a.in_dim > 1 ? cp[1] : 0.f, a.in_dim > 2 ? cp[2] : 0.f, 0.f};
       *(LDS_AS f32x4 *)(cs + tid * 16) = c;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   __syncthreads();
   FUSED_TRACE(1)
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NST];
 #pragma nounroll
   for (int l = 0; l < a.n_layers; ++l) {
     const bool mod = (a.mod_mask >> l) & 1u;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       f32x4 v[4];
       // modulated layer: scale branch first; s is stored (the backward needs it) and kept as packed bf16 --
       // the phase below uses exactly the value the backward will read
-      bf16x8 sp[4][2];
+      bf16x8 sp[NST][2];
       if (mod) {
         feature_vec(bs, a.lb_bl[l], fb_l, v);
         fill_acc(acc, v);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
         FUSED_TRACE(2 + 8 * l)
         char *S = (char *)(a.saved + a.slot * a.sv_s[l] + n0 * a.HP);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NST; ++st) {
           float sv[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) sv[j] = acc[j >> 2][st][j & 3];
@@ -302,14 +308,14 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       fill_acc(acc, v);
       if (l == 0) {
         // first layer: K = in_dim <= 3 on the VALU in fp32, operands from LDS
-        f32x4 c[4];
+        f32x4 c[NST];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) c[st] = *(const LDS_AS f32x4 *)(cs + (16 * st + i_l) * 16);
+        for (int st = 0; st < NST; ++st) c[st] = *(const LDS_AS f32x4 *)(cs + (16 * st + i_l) * 16);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const f32x4 w = *(const LDS_AS f32x4 *)(bs + (a.lb_total + (fb_l + j) * 4) * 4);
 #pragma unroll
-          for (int st = 0; st < 4; ++st) acc[j >> 2][st][j & 3] += w[0] * c[st][0] + w[1] * c[st][1] + w[2] * c[st][2];
+          for (int st = 0; st < NST; ++st) acc[j >> 2][st][j & 3] += w[0] * c[st][0] + w[1] * c[st][1] + w[2] * c[st][2];
         }
       } else {
         run_seg(acc, r, xs, a.xrow, a.xsteps, i_l, gk, lane16);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
         feature_vec(bs, a.lb_bl[l] + a.HP, fb_l, bt);
         char *Z = (char *)(a.saved + a.slot * a.sv_z[l] + n0 * a.HP);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NST; ++st) {
           float zv[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) zv[j] = acc[j >> 2][st][j & 3];
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
       char *C = (char *)(a.saved + a.slot * a.sv_c[l] + n0 * a.HP);
       const int c0 = fb_l >> 3;
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
+      for (int st = 0; st < NST; ++st) {
         float yv[16], cv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   }
 
   // final linear (siren.py:61): out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]; wave w < 4 takes sample tile w
-  if (wave < 4) {
+  if (wave < NST) {
     const int st = wave, KT = a.HP + a.LP;
     f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
     const char *wrow = (const char *)a.wf;
@@ -412,6 +418,11 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
   FUSED_TRACE(127)
 }
 
+__global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
+  if ((int)blockIdx.x < a.g4) fused_fwd_body<4>(a, 64L * blockIdx.x);
+  else fused_fwd_body<3>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
+}
+
 
 // ----------------------------------------------------------------------------------------
 // fused backward chain: the mirror of k_fused_fwd.  The gradient tile g = dz_{l+1} [64 x HP] stays in LDS from the
@@ -420,6 +431,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
 // GEMMs, reduces the bias gradients and leaves dz in LDS as the next g.
 // ----------------------------------------------------------------------------------------
 struct FusedBwdArgs {
+  int g4;                            // workgroups [0, g4) own 64 samples, the rest 48 (fused_launch_plan)
   const bf16_t *stream; long slab_elems;
   const float *side_w0;              // [HP][4] first-layer weights, then [16][HP] final_linear.weight[:, :H]
   const float *dout; const float *coords_t;
@@ -431,8 +443,8 @@ struct FusedBwdArgs {
   float om_first, om_hidden;
 };
 
-template <bool MOD, bool FIRST>
-__device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)[4][4], int l, float omega, long n0,
+template <bool MOD, bool FIRST, int NST>
+__device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)[4][NST], int l, float omega, long n0,
                                              unsigned toff_l, unsigned tstep, unsigned fb_l, int i_l, int g, int lane,
                                              lds_char *gs, const lds_char *w0s, const lds_char *cs) {
       const char *C = (const char *)(a.saved + a.slot * a.sv_c[l] + n0 * a.HP);
@@ -446,7 +458,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
       // right away, so only one scalar per tensor stays live across the tiles instead of 16
       float tz = 0.f, ts = 0.f, tt = 0.f, tw[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
+      for (int st = 0; st < NST; ++st) {
         const unsigned o = toff_l + st * tstep;
         float cv[16], dz[16];
         {
@@ -541,7 +553,8 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
       }
 }
 
-__global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
+template <int NST>
+__device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long n0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *gs = (lds_char *)smem;                       // g tile [64][xrow] bf16, swizzled
   lds_char *w0s = gs + FUSED_TS * a.xrow;                // [HP][4] fp32
@@ -551,7 +564,6 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4, gk = g;
-  const long n0 = (long)blockIdx.x * FUSED_TS;
   const int slab = wave;
   const bool active = slab * 64 < a.HP;
   const unsigned fb = slab * 64 + 16 * g;
@@ -564,11 +576,11 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
   {
     const int nb4 = 20 * a.HP / 4;
     for (int q = tid; q < nb4; q += 512) *(LDS_AS f32x4 *)(w0s + q * 16) = *reinterpret_cast<const f32x4 *>(a.side_w0 + q * 4);
-    for (int q = tid; q < FUSED_TS * 16; q += 512) {
+    for (int q = tid; q < NST * 16 * 16; q += 512) {
       const int row = q >> 4, o = q & 15;
       ((LDS_AS float *)ds_)[q] = o < a.out_dim ? a.dout[(n0 + row) * a.out_dim + o] : 0.f;
     }
-    if (tid < FUSED_TS) {
+    if (tid < NST * 16) {
       const float *cp = a.coords_t + (n0 + tid) * a.in_dim;
       f32x4 c = {cp[0], a.in_dim > 1 ? cp[1] : 0.f, a.in_dim > 2 ? cp[2] : 0.f, 0.f};
       *(LDS_AS f32x4 *)(cs + tid * 16) = c;
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
   }
   __syncthreads();
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NST];
 #pragma nounroll
   for (int l = a.n_layers - 1; l >= 0; --l) {
     const bool mod = (a.mod_mask >> l) & 1u;
@@ -593,18 +605,18 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int st = 0; st < 4; ++st) acc[ft][st] = zero4;
+        for (int st = 0; st < NST; ++st) acc[ft][st] = zero4;
       if (l == a.n_layers - 1) {
         // top of the chain: dy[n][f] = sum_o dOut[n][o] * Wf[o][f] on the VALU
         for (int o = 0; o < a.out_dim; ++o) {
-          float d[4];
+          float d[NST];
 #pragma unroll
-          for (int st = 0; st < 4; ++st) d[st] = ((const LDS_AS float *)ds_)[(16 * st + i_l) * 16 + o];
+          for (int st = 0; st < NST; ++st) d[st] = ((const LDS_AS float *)ds_)[(16 * st + i_l) * 16 + o];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 w = *(const LDS_AS f32x4 *)(wfs + ((o * a.HP + fb_l) * 4u + q * 16u));
 #pragma unroll
-            for (int st = 0; st < 4; ++st) acc[q][st] += w * d[st];
+            for (int st = 0; st < NST; ++st) acc[q][st] += w * d[st];
           }
         }
       } else {
@@ -614,15 +626,20 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
     __syncthreads();  // every wave has finished reading g
     if (active) {
       if (l == 0) {
-        if (mod) bwd_epilogue<true, true>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, true>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, true, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, true, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       } else {
-        if (mod) bwd_epilogue<true, false>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, false>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, false, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, false, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       }
     }
     __syncthreads();  // g of the next (lower) layer is complete
   }
+}
+
+__global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
+  if ((int)blockIdx.x < a.g4) fused_bwd_body<4>(a, 64L * blockIdx.x);
+  else fused_bwd_body<3>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
 
 }  // namespace
@@ -707,6 +724,31 @@ extern "C" int cinema_debug_fused_trace(int block, int wave, long long *host_out
   return 0;
 }
 
+// Launch plan of the chain kernels: Npad rows as g4 workgroups of 64 samples followed by g3 workgroups of 48, ONE launch.
+// One workgroup per CU is resident and a workgroup's time is its (sample-count independent) weight stream plus the
+// epilogues of its samples.  A batch that fills the chip between one and two times (cfg-D: 392 tiles of 64 on 256 CUs)
+// pays two weight streams per CU either way; with 48-sample tiles behind the first chip filling the second stream
+// carries three quarters of the epilogue traffic: forward 234 -> 222 us, backward chain 291 -> 271 us.  (As two
+// launches it LOSES: a lone first round of 254 workgroups in lockstep takes 180 us in the backward -- all epilogues hit
+// HBM at once -- where the mixed launch lets early finishers start the short tiles.  A delayed start of every other
+// workgroup, meant to desynchronise the phases, changed nothing.)  CINEMA_FUSED_SPLIT=0 keeps 64-sample tiles only.
+static void fused_launch_plan(int64_t Npad, int *g4, int *g3) {
+  static int ncu = 0;
+  static const bool enabled = [] { const char *e = getenv("CINEMA_FUSED_SPLIT"); return !(e && e[0] == '0'); }();
+  if (!ncu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      ncu = 256;
+  }
+  const long units = Npad / 16;                      // Npad is a multiple of 64
+  *g4 = (int)(units / 4); *g3 = 0;
+  if (!enabled || units <= 4L * ncu) return;
+  for (int c = ncu; c > ncu - 3 && c > 0; --c) {
+    const long rest = units - 4L * c;
+    if (rest > 0 && rest % 3 == 0 && rest / 3 <= ncu) { *g4 = c; *g3 = (int)(rest / 3); return; }
+  }
+}
+
 int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                   const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "fused_forward: descriptor not planned for the fused path");
@@ -739,7 +781,9 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
     CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_smem = smem;
   }
-  hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(Npad / FUSED_TS)), dim3(512), smem, s, a);
+  int g3;
+  fused_launch_plan(Npad, &a.g4, &g3);
+  hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   (void)N;
   return 0;
@@ -773,7 +817,9 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
     CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_smem = smem;
   }
-  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(Npad / FUSED_TS)), dim3(512), smem, s, a);
+  int g3;
+  fused_launch_plan(Npad, &a.g4, &g3);
+  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

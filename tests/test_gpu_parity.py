@@ -237,6 +237,17 @@ def test_oracle_parity_wide_latent_257():
     assert not bad, f"{bad}\nall: {errs}"
 
 
+@pytest.mark.parametrize("n", [16400, 25000])
+def test_oracle_parity_mixed_chain_tiles(n):
+    """bf16, batch between one and two chip fillings of 64-sample workgroups (256 CUs x 64 = 16 384): the chain kernels
+    then run ~256 workgroups of 64 samples followed by 48-sample ones in one launch (fused_launch_plan).  Ragged N, the
+    bench's batch size and the smallest batch that takes the plan."""
+    errs = _oracle_case(N=n, S=11, latent_dim=[32, 3, 3, 3], hidden=128, layers=3, mod=[1, 3], out_dim=[2, 10], cond=0,
+                        seed=31, precision="bf16", tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_oracle_parity_large_batch_grouping_path():
     """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
     errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,
