@@ -1,5 +1,5 @@
 """GPU tests of the layers above the decoder: atlas generation (mean latent -> dense inference -> post-processing,
-build_atlas.py:159-219) and the data-parallel trainer step with two ranks sharing the one GPU of the test box."""
+build_atlas.py:159-219).  The two-rank trainer step lives in tests/test_zz_gpu_two_rank.py."""
 import os
 import socket
 import sys
@@ -85,62 +85,3 @@ def test_generate_atlas_writes_the_reference_file_set(tmp_path):
             assert img.shape == (12, 12, 12, 2) and img.get_data_dtype() == np.float32
             assert np.array_equal(img.get_fdata(), vol[..., i, c, :].numpy().astype(np.float64), equal_nan=True)
             assert np.array_equal(np.diag(img.affine), [5.0, 5.0, 5.0, 1.0])
-
-
-# ------------------------------------------------------------------------------------------------
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _trainer_args():
-    return {
-        "inr_decoder": {"in_dim": 3, "out_dim": [2, 10], "latent_dim": [32, 3, 3, 3], "cond_dims": 0, "hidden_size": 128,
-                        "num_hidden_layers": 3, "modulated_layers": [1, 3], "omega": [30, 30], "cnn_kernel_size": 0,
-                        "tf_dim": 6, "precision": "fp32"},
-        "optimizer": {"tf_weight": 0.0, "loss_metric": "mse", "seg_weight": 1.0, "lr_inr": 1e-4, "inr_weight_decay": 0.0,
-                      "lr_latent": 5e-4, "latent_weight_decay": 0.0, "lr_tf": 7.5e-3, "tf_weight_decay": 0.0,
-                      "scheduler": {"type": "cosine", "eta_min": 2.5e-5}},
-        "dataset": {"class_weights": None, "world_bbox": [155, 155, 155], "label_names": []},
-        "epochs": {"train": 5, "val": 5}, "mask_reconstruction": False, "device": DEV,
-    }
-
-
-def _dp_worker(rank, port, out_dir):
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=2)     # both ranks share the one GPU: gloo moves the gradient
-    try:
-        from cinema_amd.trainer import HotPathTrainer, SubjectStore
-        torch.manual_seed(100 + rank)                              # different MLP init per rank: rank 0's must win
-        store = SubjectStore.synthetic(2, (20, 20, 20), 155.0 / 20, [155, 155, 155], 2, 10, seed=50 + rank, device=DEV)
-        store.shuffle(torch.Generator(device=DEV).manual_seed(7 + rank))
-        tr = HotPathTrainer(_trainer_args(), store, DEV, keep_grads=True)
-        flat0 = tr.eng.flat.detach().cpu().clone()
-        n = 512
-        tr.step(0, n)
-        torch.cuda.synchronize()
-        out = {"flat0": flat0, "flat1": tr.eng.flat.detach().cpu(), "grad": tr.eng.flat_grad.detach().cpu(),
-               "loss": tr.loss_dict()["total"]}
-        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_rank_trainer_step_on_one_gpu(tmp_path):
-    """Two processes, subjects sharded, MLP replicated: after one step both replicas hold identical weights, started
-    from rank 0's initialisation, and the all-reduced gradient is the mean of the two local gradients."""
-    import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_dp_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
-    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
-    assert torch.equal(r0["flat0"], r1["flat0"])                   # broadcast at construction
-    assert torch.equal(r0["grad"], r1["grad"])                     # the averaged gradient is the same tensor on both
-    assert torch.equal(r0["flat1"], r1["flat1"])                   # replicas stay bit-identical after AdamW
-    assert not torch.equal(r0["flat0"], r0["flat1"])
-    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"]) and r0["loss"] != r1["loss"]   # different shards
-    # the numerical identity of the averaged gradient with the union-batch gradient is covered on the CPU by
-    # tests/test_dp_gloo.py (same helper, gloo backend)
