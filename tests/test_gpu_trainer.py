@@ -239,3 +239,50 @@ def test_sorted_k1_forward_is_bit_identical(precision, tf_dim, cond_dims, order)
     # no embedding table at all: coordinates pass through
     E.k1_forward_sorted(eng, coords, idx, latents, cond, None, n)
     assert torch.equal(ws.coords_t[:n], coords)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_validation_split_step_matches_oracle(precision):
+    """split='val' (build_atlas.py:63,74,99-126,423-425): the MLP is frozen (dX-only backward), seg_weight = 0, the
+    per-subject condition rows are learnable.  Gradients of latents / transformations / conditions == CPU oracle, the
+    MLP does not move, the tables move as torch.optim.AdamW moves them."""
+    from oracle import cinema_oracle as O
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 1, precision, tf_weight=0.0)
+    torch.manual_seed(33)
+    store = SubjectStore.synthetic(4, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=9, device=DEV, cond_dims=1)
+    n = 600
+    store.shuffle(torch.Generator(device=DEV).manual_seed(2), group_chunk=n)
+    tr = HotPathTrainer(args, store, DEV, split="val", keep_grads=True)
+    assert tr.cond_param is not None and not tr.train_mlp and tr.seg_weight == 0.0
+    with torch.no_grad():
+        tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(6)) - 0.5) * 0.05)
+        tr.cond_param.copy_(torch.randn(tr.cond_param.shape, generator=torch.Generator().manual_seed(7)) * 0.05)
+    lat0, tf0, c0 = (x.detach().cpu().clone() for x in (tr.latents, tr.tfs, tr.cond_param))
+    flat0 = tr.eng.flat.detach().cpu().clone()
+    coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
+    base = subj.long() * store.V + voxel
+    target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
+    lat_o, tf_o, c_o = (x.clone().requires_grad_(True) for x in (lat0, tf0, c0))
+    cond_rows = c_o[subj.long()]
+    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse",
+               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0, seg_weight=0.0)
+    loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, cond_rows, cfg)
+    tr.step(0, n)
+    got = tr.loss_dict()
+    assert abs(got["total"] - float(loss_o["total"])) < tol * abs(float(loss_o["total"]))
+    errs = {"glat": rel_err(tr.lat_grad.cpu().numpy(), lat_o.grad.numpy()),
+            "gtf": rel_err(tr.tf_grad.cpu().numpy(), tf_o.grad.numpy()),
+            "gcond": rel_err(tr.cond_param.grad.cpu().numpy(), c_o.grad.numpy())}
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+    assert torch.equal(tr.eng.flat.detach().cpu(), flat0)           # frozen MLP
+    ref_p = [torch.nn.Parameter(lat0.clone()), torch.nn.Parameter(tf0.clone()), torch.nn.Parameter(c0.clone())]
+    ref_p[0].grad, ref_p[1].grad, ref_p[2].grad = tr.lat_grad.cpu(), tr.tf_grad.cpu(), tr.cond_param.grad.cpu()
+    torch.optim.AdamW([{"params": [ref_p[0]], "lr": 5e-4, "weight_decay": 0.0},
+                       {"params": [ref_p[1]], "lr": 7.5e-3, "weight_decay": 0.0},
+                       {"params": [ref_p[2]], "lr": 5e-4, "weight_decay": 0.0}]).step()
+    for x, r in ((tr.latents, ref_p[0]), (tr.tfs, ref_p[1]), (tr.cond_param, ref_p[2])):
+        assert rel_err(x.detach().cpu().numpy(), r.detach().numpy()) < 1e-5
