@@ -286,3 +286,33 @@ def test_validation_split_step_matches_oracle(precision):
                        {"params": [ref_p[2]], "lr": 5e-4, "weight_decay": 0.0}]).step()
     for x, r in ((tr.latents, ref_p[0]), (tr.tfs, ref_p[1]), (tr.cond_param, ref_p[2])):
         assert rel_err(x.detach().cpu().numpy(), r.detach().numpy()) < 1e-5
+
+
+def test_epoch_walks_the_whole_list_and_steps_the_schedule():
+    """HotPathTrainer.epoch (build_atlas.py:65-68, 455-463): ceil(m / n_samples) steps including the ragged last one,
+    every chunk grouped by subject (the grouped K1 kernels take them), cosine schedule stepped once per epoch."""
+    import math
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([32, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, "bf16")
+    torch.manual_seed(8)
+    store = SubjectStore.synthetic(3, (16, 16, 16), 155.0 / 16, [155, 155, 155], 2, 10, seed=12, device=DEV)
+    tr = HotPathTrainer(args, store, DEV)
+    m, n = len(store), 1000
+    assert m % n != 0
+    lat0, flat0 = tr.latents.detach().clone(), tr.eng.flat.detach().clone()
+    steps = tr.epoch(n, generator=torch.Generator(device=DEV).manual_seed(3))
+    assert steps == math.ceil(m / n)
+    assert store.group_chunk == n
+    for lo in range(0, m, n):
+        chunk = store.subj[lo:lo + n]
+        assert bool((chunk[1:] >= chunk[:-1]).all())
+    assert tr.n_last == m - (steps - 1) * n                          # the ragged last batch
+    loss = tr.loss_dict()
+    assert np.isfinite(loss["total"]) and loss["total"] > 0
+    assert not torch.equal(tr.latents.detach(), lat0) and not torch.equal(tr.eng.flat.detach(), flat0)
+    assert bool(torch.isfinite(tr.eng.flat).all()) and bool(torch.isfinite(tr.latents).all())
+    o = args["optimizer"]
+    want = o["scheduler"]["eta_min"] + (o["lr_inr"] - o["scheduler"]["eta_min"]) * (1 + math.cos(math.pi / args["epochs"]["train"])) / 2
+    lrs = [g["lr"] for g in tr.opt_local.param_groups]
+    assert abs(lrs[-1] - want) < 1e-12 * max(1.0, want) + 1e-15, (lrs, want)
+    assert tr.epoch(n, generator=torch.Generator(device=DEV).manual_seed(4), max_steps=2) == 2
