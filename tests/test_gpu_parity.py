@@ -248,6 +248,16 @@ def test_oracle_parity_mixed_chain_tiles(n):
     assert not bad, f"{bad}\nall: {errs}"
 
 
+def test_oracle_parity_full_bench_shape():
+    """The configuration the bench line is quoted on, at full size (BASELINE.json cfg-D: latent 256 x 3^3, hidden 512,
+    5 hidden layers, modulated 1/3/5, out 2 + 10, 64 subjects, n_samples = 25 000), bf16, against the CPU oracle:
+    mixed 64 / 48-sample chain tiles, 256 x 256 weight-gradient tiles with 7 sample splits, the wide d-latent GEMM."""
+    errs = _oracle_case(N=25000, S=64, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[2, 10],
+                        cond=0, seed=41, precision="bf16", tf_table=True)
+    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_oracle_parity_large_batch_grouping_path():
     """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
     errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,

@@ -89,30 +89,41 @@ def test_g7_adamw_trajectory_golden():
         assert np.abs(p.detach().cpu().numpy() - g["q_" + n]).max() < 2e-2 * max(move, 1e-12), n
 
 
-@pytest.mark.parametrize("precision,grouped", [("fp32", False), ("bf16", False), ("fp32", True)])
+@pytest.mark.parametrize("precision,grouped", [("fp32", False), ("bf16", False), ("fp32", True), ("bf16", True)])
 def test_trainer_step_matches_oracle(precision, grouped):
     """The autograd-free step: gradients it leaves behind == CPU oracle on the same samples (targets gathered from
     the resident volumes: labels bit-exact), and the parameters move as torch.optim.AdamW would move them."""
+    _trainer_step_vs_oracle(precision, grouped, S=5, side=24, latent_dim=[48, 3, 3, 3], hidden=128, layers=3, mod=[1, 3], n=700)
+
+
+def test_trainer_step_matches_oracle_full_bench_shape():
+    """The same at the size the bench line is quoted on (cfg-D: 64 subjects, latent 256 x 3^3, hidden 512, 5 hidden
+    layers modulated 1/3/5, n_samples 25 000, bf16, batch grouped by subject): the grouped K1 kernels over 64 subjects,
+    the 64 / 48-sample chain tiles, the side-stream preparation with the class-weight normaliser at full batch size."""
+    _trainer_step_vs_oracle("bf16", True, S=64, side=28, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], n=25000)
+
+
+def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, layers, mod, n):
     from oracle import cinema_oracle as O
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
     tol = 1e-4 if precision == "fp32" else 2e-2
-    args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
+    args = base_args(latent_dim, hidden, layers, mod, [2, 10], 0, precision, tf_weight=0.0)
     torch.manual_seed(21)
-    store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
-    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700 if grouped else None)
-    if grouped:      # every step-sized chunk is sorted by subject -> the sorted K1 backward entry point is taken
-        assert bool((store.subj[:700][1:] >= store.subj[:700][:-1]).all()) and bool((store.subj[700:1400][1:] >= store.subj[700:1400][:-1]).all())
+    store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 2, 10, seed=7, device=DEV)
+    assert len(store) >= 2 * n
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n if grouped else None)
+    if grouped:      # every step-sized chunk is sorted by subject -> the grouped K1 entry points are taken
+        assert bool((store.subj[:n][1:] >= store.subj[:n][:-1]).all()) and bool((store.subj[n:2 * n][1:] >= store.subj[n:2 * n][:-1]).all())
     tr = HotPathTrainer(args, store, DEV, keep_grads=True)
     with torch.no_grad():
         tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
-    n = 700
     lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()
     coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
     base = subj.long() * store.V + voxel
     target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
     params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
     lat_o, tf_o = lat0.clone().requires_grad_(True), tf0.clone().requires_grad_(True)
-    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse",
+    cfg = dict(num_hidden_layers=layers, omega=[30, 30], sr_dims=2, loss_metric="mse",
                class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0)
     loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, None, cfg)
     # K3 sampled exactly these targets (bit-exact labels and intensities)
