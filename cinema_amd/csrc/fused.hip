@@ -53,14 +53,15 @@ void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
 struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1; };
 
 __global__ void k_pack_stream(PackStreamArgs a) {
-  const long n0 = (long)a.nslab * a.steps0 * 256, nchunk = n0 + (long)a.nslab * a.steps1 * 256;
-  for (long qq = (long)blockIdx.x * blockDim.x + threadIdx.x; qq < nchunk; qq += (long)gridDim.x * blockDim.x) {
+  // 32-bit indices (the host checks the range): two 64-bit divisions per 16-byte chunk were a third of this kernel
+  const unsigned n0 = (unsigned)a.nslab * a.steps0 * 256u, nchunk = n0 + (unsigned)a.nslab * a.steps1 * 256u;
+  for (unsigned qq = blockIdx.x * blockDim.x + threadIdx.x; qq < nchunk; qq += gridDim.x * blockDim.x) {
     const bool second = qq >= n0;
-    const long q = second ? qq - n0 : qq;
+    const unsigned q = second ? qq - n0 : qq;
     const int steps = second ? a.steps1 : a.steps0, sbeg = second ? a.nseg0 : 0, send = second ? a.nseg0 + a.nseg1 : a.nseg0;
     const int lane = (int)(q & 63), ft = (int)((q >> 6) & 3);
-    const long sq = q >> 8;
-    const int step = (int)(sq % steps), slab = (int)(sq / steps);
+    const unsigned sq = q >> 8;
+    const int slab = (int)(sq / (unsigned)steps), step = (int)(sq - (unsigned)slab * (unsigned)steps);
     int si = sbeg;
     while (si + 1 < send && step >= a.seg[si + 1].step0) ++si;
     const Seg sg = a.seg[si];
@@ -76,7 +77,7 @@ __global__ void k_pack_stream(PackStreamArgs a) {
       if (feat < sg.rows && k < sg.cols) x = sg.transpose ? src[(long)k * sg.ld + feat] : src[(long)feat * sg.ld + k];
       v[j] = (bf16_t)x;
     }
-    *reinterpret_cast<bf16x8 *>((second ? a.dst1 : a.dst0) + q * 8) = v;
+    *reinterpret_cast<bf16x8 *>((second ? a.dst1 : a.dst0) + (size_t)q * 8) = v;
   }
 }
 
@@ -692,6 +693,7 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
     a.params = params;
     a.dst0 = (bf16_t *)packed + d->pk_fs; a.dst1 = (bf16_t *)packed + d->pk_bs;
     const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
+    CINEMA_REQUIRE(nchunk < (1L << 31), "fused_pack: weight streams too large for 32-bit chunk indices");
     if (nchunk > 0) {
       const int grid = (int)std::min<long>((nchunk + 255) / 256, 4096);
       hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
