@@ -14,6 +14,8 @@
 
 namespace {
 
+#include "k1_device.h"
+
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
 inline int ksteps(int k) { return round_up_i(k / 32, FUSED_RING); }   // k32 steps of a segment, padded to the ring
 
@@ -52,10 +54,12 @@ void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
 // two streams (forward, backward chain) packed by one launch: segments [0, nseg0) belong to stream 0
 struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1; };
 
-__global__ void k_pack_stream(PackStreamArgs a) {
-  // 32-bit indices (the host checks the range): two 64-bit divisions per 16-byte chunk were a third of this kernel
+// (vbid, vgrid): the workgroup's index and count among the workgroups doing this job -- the kernels below run either
+// as launches of their own or as block ranges of k_step_head
+__device__ __forceinline__ void pack_stream_body(const PackStreamArgs &a, unsigned vbid, unsigned vgrid) {
+  // 32-bit indices (the host checks the range)
   const unsigned n0 = (unsigned)a.nslab * a.steps0 * 256u, nchunk = n0 + (unsigned)a.nslab * a.steps1 * 256u;
-  for (unsigned qq = blockIdx.x * blockDim.x + threadIdx.x; qq < nchunk; qq += gridDim.x * blockDim.x) {
+  for (unsigned qq = vbid * 256u + threadIdx.x; qq < nchunk; qq += vgrid * 256u) {
     const bool second = qq >= n0;
     const unsigned q = second ? qq - n0 : qq;
     const int steps = second ? a.steps1 : a.steps0, sbeg = second ? a.nseg0 : 0, send = second ? a.nseg0 + a.nseg1 : a.nseg0;
@@ -80,6 +84,7 @@ __global__ void k_pack_stream(PackStreamArgs a) {
     *reinterpret_cast<bf16x8 *>((second ? a.dst1 : a.dst0) + (size_t)q * 8) = v;
   }
 }
+__global__ __launch_bounds__(256) void k_pack_stream(PackStreamArgs a) { pack_stream_body(a, blockIdx.x, gridDim.x); }
 
 // fp32 side block in exactly the layout the forward kernel keeps in LDS (zero padded to HP per vector):
 //   per layer [b_l] [bl_scale, bl_shift if modulated] ... then w0 as [HP][4] (k = 0..2, pad), then (backward only)
@@ -93,10 +98,10 @@ struct PackSideArgs {
   bf16_t *dst_wf; int LP;      // final_linear padded to [16][HP + LP] bf16 (read by the forward's last layer)
 };
 
-__global__ void k_pack_side(PackSideArgs a) {
+__device__ __forceinline__ void pack_side_body(const PackSideArgs &a, unsigned vbid, unsigned vgrid) {
   const int total = a.lb_total + 4 * a.HP + 16 * a.HP;
   const int total_wf = 16 * (a.HP + a.LP);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + total_wf; e += gridDim.x * blockDim.x) {
+  for (int e = vbid * 256u + threadIdx.x; e < total + total_wf; e += vgrid * 256u) {
     float x = 0.f;
     if (e >= total) {
       const int q = e - total, o = q / (a.HP + a.LP), col = q - o * (a.HP + a.LP);
@@ -122,6 +127,18 @@ __global__ void k_pack_side(PackSideArgs a) {
     }
     a.dst[e] = x;
   }
+}
+__global__ __launch_bounds__(256) void k_pack_side(PackSideArgs a) { pack_side_body(a, blockIdx.x, gridDim.x); }
+
+// The head of a training step in ONE launch: the grouped-batch K1 forward and the forward half of the repacking are
+// independent but would share a stream as separate kernels (23 + 17 us in a row; a second stream costs a 6-10 us join).
+// Block ranges: [0, g_k1) K1 forward chunks, then the weight-stream chunks, then the side block.
+struct StepHeadArgs { PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1; int g_k1, g_ps, g_sd; };
+__global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
+  const int b = blockIdx.x;                      // workgroup-uniform dispatch
+  if (b < a.g_k1) trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b);
+  else if (b < a.g_k1 + a.g_ps) pack_stream_body(a.ps, b - a.g_k1, a.g_ps);
+  else pack_side_body(a.sd, b - a.g_k1 - a.g_ps, a.g_sd);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -679,28 +696,21 @@ void fused_plan(cinema_siren_desc *d, long *pk) {
   *pk += 2L * (fused_bias_floats(d) + 4 * d->HP + 16 * d->HP);
 }
 
-int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
-  if (d->pk_fs < 0) return 0;
-  {
-    StreamPlan p0, p1;
-    plan_fwd_stream(d, p0);
-    plan_bwd_stream(d, p1);
-    PackStreamArgs a;
-    CINEMA_REQUIRE(p0.nseg + p1.nseg <= FUSED_MAX_SEGS, "fused_pack: %d segments exceed the table", p0.nseg + p1.nseg);
-    for (int k = 0; k < p0.nseg; ++k) a.seg[k] = p0.seg[k];
-    for (int k = 0; k < p1.nseg; ++k) a.seg[p0.nseg + k] = p1.seg[k];
-    a.nseg0 = p0.nseg; a.nseg1 = p1.nseg; a.steps0 = p0.steps; a.steps1 = p1.steps; a.nslab = d->HP / 64;
-    a.params = params;
-    a.dst0 = (bf16_t *)packed + d->pk_fs; a.dst1 = (bf16_t *)packed + d->pk_bs;
-    const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
-    CINEMA_REQUIRE(nchunk < (1L << 31), "fused_pack: weight streams too large for 32-bit chunk indices");
-    if (nchunk > 0) {
-      const int grid = (int)std::min<long>((nchunk + 255) / 256, 4096);
-      hipLaunchKernelGGL(k_pack_stream, dim3(grid), dim3(256), 0, s, a);
-      CINEMA_CHECK_HIP(hipGetLastError());
-    }
-  }
-  PackSideArgs b = {};
+static int fused_pack_args(const cinema_siren_desc *d, const float *params, void *packed, PackStreamArgs &a, PackSideArgs &b,
+                           int &g_ps, int &g_sd) {
+  StreamPlan p0, p1;
+  plan_fwd_stream(d, p0);
+  plan_bwd_stream(d, p1);
+  CINEMA_REQUIRE(p0.nseg + p1.nseg <= FUSED_MAX_SEGS, "fused_pack: %d segments exceed the table", p0.nseg + p1.nseg);
+  for (int k = 0; k < p0.nseg; ++k) a.seg[k] = p0.seg[k];
+  for (int k = 0; k < p1.nseg; ++k) a.seg[p0.nseg + k] = p1.seg[k];
+  a.nseg0 = p0.nseg; a.nseg1 = p1.nseg; a.steps0 = p0.steps; a.steps1 = p1.steps; a.nslab = d->HP / 64;
+  a.params = params;
+  a.dst0 = (bf16_t *)packed + d->pk_fs; a.dst1 = (bf16_t *)packed + d->pk_bs;
+  const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
+  CINEMA_REQUIRE(nchunk < (1L << 31), "fused_pack: weight streams too large for 32-bit chunk indices");
+  g_ps = (int)std::min<long>((nchunk + 255) / 256, 4096);
+  b = PackSideArgs{};
   b.params = params; b.dst = (float *)((bf16_t *)packed + d->pk_side);
   for (int i = 0; i < d->n_layers; ++i) {
     b.off_b[i] = d->off_b[i]; b.off_bl[i] = d->off_bl[i];
@@ -712,7 +722,43 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
   b.mod_mask = d->modulated_mask; b.n_layers = d->n_layers; b.H = d->hidden; b.HP = d->HP; b.in_dim = d->in_dim;
   b.off_wf = d->off_wf; b.out_dim = d->out_dim; b.lat = d->lat;
   b.dst_wf = (bf16_t *)packed + d->pk_wf; b.LP = d->LP;
-  hipLaunchKernelGGL(k_pack_side, dim3((b.lb_total + 20 * d->HP + 16 * (d->HP + d->LP) + 255) / 256), dim3(256), 0, s, b);
+  g_sd = (b.lb_total + 20 * d->HP + 16 * (d->HP + d->LP) + 255) / 256;
+  return 0;
+}
+
+int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
+  if (d->pk_fs < 0) return 0;
+  PackStreamArgs a;
+  PackSideArgs b;
+  int g_ps = 0, g_sd = 0;
+  if (int rc = fused_pack_args(d, params, packed, a, b, g_ps, g_sd)) return rc;
+  if (g_ps > 0) {
+    hipLaunchKernelGGL(k_pack_stream, dim3(g_ps), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_pack_side, dim3(g_sd), dim3(256), 0, s, b);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params, void *packed, const float *coords,
+                                const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
+                                int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                                int32_t cond_dims, float *coords_t, void *lat_out, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords && idx && latents && coords_t && lat_out, "cinema_step_head: null argument");
+  CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "cinema_step_head: needs the activation-stationary bf16 path (hidden <= 512)");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_step_head: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
+  CINEMA_REQUIRE(lx == 3 && ly == 3 && lz == 3 && C >= 4 && C <= TFS_CMAX && C % 4 == 0 && d->LP % 4 == 0,
+                 "cinema_step_head: needs the 3x3x3 grid, C <= %d, C %% 4 == 0 (got %d x %d x %d x %d)", TFS_CMAX, C, lx, ly, lz);
+  CINEMA_REQUIRE(embed == nullptr || tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
+  CINEMA_REQUIRE(cond_dims == 0 || cond != nullptr, "cond_dims %d but cond is null", cond_dims);
+  CINEMA_REQUIRE(C + cond_dims == d->lat, "cinema_step_head: C + cond_dims = %d != lat_size %d", C + cond_dims, d->lat);
+  StepHeadArgs a;
+  if (int rc = fused_pack_args(d, params, packed, a.ps, a.sd, a.g_ps, a.g_sd)) return rc;
+  a.k1 = TriFwdSortedArgs{coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, d->LP, coords_t,
+                          lat_out};
+  a.g_k1 = (int)((Npad + TFS_CHUNK - 1) / TFS_CHUNK);
+  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd)), dim3(256), 0, (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

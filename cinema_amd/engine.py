@@ -240,6 +240,19 @@ def k1_forward_sorted(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor,
           "cinema_affine_trilerp_fwd_sorted")
 
 
+def step_head(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
+              cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
+    """eng.pack(1) + k1_forward_sorted in one launch (cinema_step_head); the caller checked k1_sorted_eligible and
+    eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use)."""
+    lib, d, ws = eng.lib, eng.desc, eng.ws
+    S, Cc, lx, ly, lz = latents.shape
+    cond_dims = 0 if cond is None else cond.shape[1]
+    npad = round_up(n, ROW_ALIGN)
+    check(lib.cinema_step_head(C.byref(d), ptr(eng.flat), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
+                               0 if tfs is None else tfs.shape[1], ptr(latents), ptr(cond) if cond_dims else None, n, npad,
+                               S, Cc, lx, ly, lz, cond_dims, ptr(ws.coords_t), ptr(ws.lat), eng.stream()), "cinema_step_head")
+
+
 def k1_shadow(eng: SirenEngine, st: TrilerpState, latents: torch.Tensor):
     """Node-major shadow of the latent table for the K1 backward (on the current stream)."""
     S, Cc = latents.shape[0], latents.shape[1]

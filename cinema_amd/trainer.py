@@ -177,6 +177,15 @@ class HotPathTrainer:
         grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
 
+        one_head = fast_k1 and eng.can_skip_saved()      # grouped batch on the activation-stationary bf16 path
+
+        def head():                                   # forward half of the repacking + K1 forward
+            if one_head:
+                E.step_head(eng, coords, subj, self.latents.data, cond, tfs, n)      # ... as ONE launch
+            else:
+                eng.pack(1)
+                k1_fwd()
+
         def k1_fwd():
             if fast_k1:
                 E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
@@ -196,11 +205,10 @@ class HotPathTrainer:
             with torch.cuda.stream(side):
                 backward_only_prep()                # nothing the forward reads: beside it, joined before the loss kernel
                 self.ev_prep.record(side)
-            eng.pack(1)                             # what the forward reads stays on this stream: a cross-stream wait
-            k1_fwd()                                # costs more idle queue (6-10 us) than the overlap with K1 would save
+            head()                                  # what the forward reads stays on this stream (a cross-stream wait
+                                                    # costs 6-10 us of idle queue)
         else:
-            eng.pack(1)
-            k1_fwd()
+            head()
             backward_only_prep()
         eng.forward(n)
         if self.side is not None:

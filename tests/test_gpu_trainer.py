@@ -327,3 +327,33 @@ def test_epoch_walks_the_whole_list_and_steps_the_schedule():
     lrs = [g["lr"] for g in tr.opt_local.param_groups]
     assert abs(lrs[-1] - want) < 1e-12 * max(1.0, want) + 1e-15, (lrs, want)
     assert tr.epoch(n, generator=torch.Generator(device=DEV).manual_seed(4), max_steps=2) == 2
+
+
+def test_step_head_equals_pack_plus_sorted_forward():
+    """cinema_step_head (one launch) leaves the same bits as cinema_siren_pack_part(1) + cinema_affine_trilerp_fwd_sorted:
+    packed weight streams / side block / padded final_linear, registered coordinates, interpolated latent rows."""
+    from cinema_amd import _lib, engine as E
+    S, Cc, n = 9, 64, 3000 + 11
+    d = E.make_desc(3, Cc, 12, 256, 4, [1, 3], 30, 30, _lib.PREC_BF16)
+    eng = E.SirenEngine(d, DEV)
+    assert eng.can_skip_saved()
+    g = torch.Generator().manual_seed(17)
+    eng.flat.copy_((torch.randn(eng.flat.shape, generator=g) * 0.05).to(DEV))
+    latents = (torch.randn(S, Cc, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    tfs = ((torch.rand(S, 6, generator=g) - 0.5) * 0.2).to(DEV)
+    coords = (torch.rand(n, 3, generator=g) * 2.2 - 1.1).to(DEV)
+    idx = torch.randint(0, S, (n,), generator=g, dtype=torch.int32).sort().values.to(DEV)
+    ws = eng.workspace(n)
+    npad = E.round_up(n, 128)
+    eng.packed.zero_()
+    eng.pack(1)
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
+    E.k1_forward_sorted(eng, coords, idx, latents, None, tfs, n)
+    ref = (eng.packed.clone(), ws.coords_t[:npad].clone(), ws.lat[:npad].clone())
+    eng.packed.zero_()
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
+    E.step_head(eng, coords, idx, latents, None, tfs, n)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.packed.view(torch.int16), ref[0].view(torch.int16))
+    assert torch.equal(ws.coords_t[:npad].view(torch.int32), ref[1].view(torch.int32))
+    assert torch.equal(ws.lat[:npad].view(torch.int16), ref[2].view(torch.int16))

@@ -7,7 +7,8 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "k_pack" in n]
+head = "k_step_head" if any("k_step_head" in n for n in names) else "k_pack"   # first kernel of a step
+idx = [i for i, n in enumerate(names) if head in n]
 starts = [i for k, i in enumerate(idx) if k == 0 or idx[k - 1] != i - 1]
 a, b = starts[-back], starts[-back + 1]
 t0 = int(rows[a]["Start_Timestamp"]); prev = t0; busy = 0
