@@ -60,7 +60,7 @@ SIGNATURES = {
     "cinema_affine_trilerp_fwd_sorted": [_P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P,
                                          _I32, _P],
     "cinema_step_head": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
-                         _P, _P, _P],
+                         _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
     "cinema_affine_trilerp_bwd": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                   _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_sorted": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,

@@ -15,6 +15,7 @@
 namespace {
 
 #include "k1_device.h"
+#include "step_device.h"
 
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
 inline int ksteps(int k) { return round_up_i(k / 32, FUSED_RING); }   // k32 steps of a segment, padded to the ring
@@ -130,15 +131,32 @@ __device__ __forceinline__ void pack_side_body(const PackSideArgs &a, unsigned v
 }
 __global__ __launch_bounds__(256) void k_pack_side(PackSideArgs a) { pack_side_body(a, blockIdx.x, gridDim.x); }
 
-// The head of a training step in ONE launch: the grouped-batch K1 forward and the forward half of the repacking are
-// independent but would share a stream as separate kernels (23 + 17 us in a row; a second stream costs a 6-10 us join).
-// Block ranges: [0, g_k1) K1 forward chunks, then the weight-stream chunks, then the side block.
-struct StepHeadArgs { PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1; int g_k1, g_ps, g_sd; };
+// The head of a training step in ONE launch.  The grouped-batch K1 forward, the repacking of the weights, the node-major
+// shadow of the latent table and the per-step clearing are independent, but as separate kernels they either share a
+// stream (23 + 17 us in a row for the two the forward waits for) or need a second stream, whose join costs 6-10 us of
+// idle queue.  Block ranges: step_prepare (the longest chain of dependent loads; optional, g_pr = 0) | K1 forward chunks |
+// backward-only transposes (64 workgroups each) | weight streams | side block | shadow tiles (optional, g_nm = 0).
+#define HEAD_MAX_JOBS 8
+struct StepHeadArgs {
+  PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1;
+  PackJob job[HEAD_MAX_JOBS]; void *packed;
+  const float *nm_lat; float *nm_shadow; long nm_S; int nm_C, nm_G;
+  StepPrepareArgs pr;
+  int g_k1, g_ps, g_sd, g_job, g_nm, g_pr;
+};
 __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
-  const int b = blockIdx.x;                      // workgroup-uniform dispatch
-  if (b < a.g_k1) trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b);
-  else if (b < a.g_k1 + a.g_ps) pack_stream_body(a.ps, b - a.g_k1, a.g_ps);
-  else pack_side_body(a.sd, b - a.g_k1 - a.g_ps, a.g_sd);
+  int b = blockIdx.x;                            // workgroup-uniform dispatch; the longest dependent-load chains first
+  if (b < a.g_pr) { step_prepare_body(a.pr, b, a.g_pr); return; }
+  b -= a.g_pr;
+  if (b < a.g_k1) { trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b); return; }
+  b -= a.g_k1;
+  if (b < a.g_job) { pack_job_body<bf16_t>(a.job[b >> 6], a.packed, b & 63, 64); return; }
+  b -= a.g_job;
+  if (b < a.g_ps) { pack_stream_body(a.ps, b, a.g_ps); return; }
+  b -= a.g_ps;
+  if (b < a.g_sd) { pack_side_body(a.sd, b, a.g_sd); return; }
+  b -= a.g_sd;
+  node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -744,7 +762,9 @@ int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hi
 extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params, void *packed, const float *coords,
                                 const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                                 int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
-                                int32_t cond_dims, float *coords_t, void *lat_out, void *stream) {
+                                int32_t cond_dims, float *coords_t, void *lat_out, float *shadow, float *dcoords,
+                                int64_t n_dcoords, float *sums, const int64_t *voxel, const uint8_t *labels, int64_t V,
+                                int32_t n_cls, const float *class_w, float *scratch, void *stream) {
   CINEMA_REQUIRE(d && params && packed && coords && idx && latents && coords_t && lat_out, "cinema_step_head: null argument");
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "cinema_step_head: needs the activation-stationary bf16 path (hidden <= 512)");
   CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_step_head: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
@@ -753,12 +773,39 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
   CINEMA_REQUIRE(embed == nullptr || tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
   CINEMA_REQUIRE(cond_dims == 0 || cond != nullptr, "cond_dims %d but cond is null", cond_dims);
   CINEMA_REQUIRE(C + cond_dims == d->lat, "cinema_step_head: C + cond_dims = %d != lat_size %d", C + cond_dims, d->lat);
-  StepHeadArgs a;
+  StepHeadArgs a = {};
   if (int rc = fused_pack_args(d, params, packed, a.ps, a.sd, a.g_ps, a.g_sd)) return rc;
   a.k1 = TriFwdSortedArgs{coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, d->LP, coords_t,
                           lat_out};
   a.g_k1 = (int)((Npad + TFS_CHUNK - 1) / TFS_CHUNK);
-  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd)), dim3(256), 0, (hipStream_t)stream, a);
+  // backward-only repacking: the transposed linear_lats copies of the d-latent GEMM (cinema_siren_pack_part(.., 2))
+  int nj = 0;
+  const int H = d->hidden, L = d->lat;
+  for (int i = 0; i < d->n_layers; ++i)
+    if ((d->modulated_mask >> i) & 1u) {
+      CINEMA_REQUIRE(nj + 2 <= HEAD_MAX_JOBS, "cinema_step_head: more than %d modulated layers", HEAD_MAX_JOBS / 2);
+      const float *wl = params + d->off_wl[i];
+      a.job[nj++] = PackJob{wl, d->pk_wlsT[i], H, L, L, d->LP, d->HP, 1};
+      a.job[nj++] = PackJob{wl + (size_t)H * L, d->pk_wltT[i], H, L, L, d->LP, d->HP, 1};
+    }
+  a.packed = packed;
+  a.g_job = 64 * nj;
+  if (shadow != nullptr) {
+    const int G = lx * ly * lz;
+    a.nm_lat = latents; a.nm_shadow = shadow; a.nm_S = (long)S; a.nm_C = C; a.nm_G = G;
+    const long nwg = (long)((G + 31) / 32) * ((C + 31) / 32) * S;
+    CINEMA_REQUIRE(nwg < (1L << 24), "cinema_step_head: latent table too large (%ld tiles)", nwg);
+    a.g_nm = (int)nwg;
+  }
+  if (sums != nullptr) {
+    CINEMA_REQUIRE(scratch != nullptr && n_dcoords >= 0 && (dcoords != nullptr || n_dcoords == 0), "cinema_step_head: bad prepare arguments");
+    CINEMA_REQUIRE(class_w == nullptr || (voxel && labels && n_cls >= 1), "cinema_step_head: class_w needs the label source");
+    const long work = std::max<long>(class_w != nullptr ? (long)N : 0, (long)n_dcoords);
+    a.g_pr = (int)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
+    a.pr = StepPrepareArgs{dcoords, (long)n_dcoords, sums, voxel, idx, labels, (long)V, (long)N, n_cls, class_w, scratch};
+  }
+  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nm + a.g_pr)), dim3(256), 0,
+                     (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -7,11 +7,7 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+#include "step_device.h"
 
 __global__ void k_class_weight_sum(const float *target, int tcols, const int64_t *voxel, const int32_t *subj,
                                    const uint8_t *labels, long V, long N, int n_cls, const float *class_w, float *sums) {
@@ -25,47 +21,7 @@ __global__ void k_class_weight_sum(const float *target, int tcols, const int64_t
   if ((threadIdx.x & 63) == 0) atomicAdd(sums + 2, acc);
 }
 
-// Per-step clearing + class-weight normaliser in ONE launch: every workgroup zeroes its share of dcoords and leaves the
-// partial sum of w[label] over its samples in scratch; the workgroup that finishes last (a counter in scratch, which it
-// resets for the next call) adds the partials in workgroup order and writes sums = {0, 0, sum w, 0}.  No zero-then-
-// accumulate ordering between launches, no float atomics: the same bits every run.
-#define PREP_MAX_GRID 256
-__global__ __launch_bounds__(256) void k_step_prepare(float *dcoords, long n_dcoords, float *sums, const int64_t *voxel,
-                                                      const int32_t *subj, const uint8_t *labels, long V, long N, int n_cls,
-                                                      const float *class_w, float *scratch) {
-  __shared__ float red[4];
-  __shared__ int last;
-  const int tid = threadIdx.x;
-  float acc = 0.f;
-  if (class_w != nullptr) {
-    for (long n = (long)blockIdx.x * blockDim.x + tid; n < N; n += (long)gridDim.x * blockDim.x) {
-      int y = (int)labels[(long)subj[n] * V + voxel[n]];
-      y = y < 0 ? 0 : (y >= n_cls ? n_cls - 1 : y);
-      acc += class_w[y];
-    }
-  }
-  for (long e = (long)blockIdx.x * blockDim.x + tid; e < n_dcoords; e += (long)gridDim.x * blockDim.x) dcoords[e] = 0.f;
-  acc = wave_sum(acc);
-  if ((tid & 63) == 0) red[tid >> 6] = acc;
-  __syncthreads();
-  unsigned int *counter = reinterpret_cast<unsigned int *>(scratch + PREP_MAX_GRID);
-  if (tid == 0) {
-    scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    __threadfence();
-    last = atomicAdd(counter, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (last && tid < 64) {
-    __threadfence();
-    float t = 0.f;
-    for (int b = tid; b < (int)gridDim.x; b += 64) t += __builtin_nontemporal_load(scratch + b);
-    t = wave_sum(t);
-    if (tid == 0) {
-      sums[0] = 0.f; sums[1] = 0.f; sums[2] = t; sums[3] = 0.f;
-      *counter = 0u;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void k_step_prepare(StepPrepareArgs a) { step_prepare_body(a, blockIdx.x, gridDim.x); }
 
 struct LossArgs {
   const float *out; const float *target; const int64_t *voxel; const int32_t *subj; const float *intens;
@@ -260,8 +216,8 @@ extern "C" int cinema_step_prepare(float *dcoords, int64_t n_dcoords, float *sum
                  "cinema_step_prepare: class_w needs the label source");
   const long work = std::max<long>(class_w != nullptr ? (long)N : 0, (long)n_dcoords);
   const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
-  hipLaunchKernelGGL(k_step_prepare, dim3(grid), dim3(256), 0, (hipStream_t)stream, dcoords, (long)n_dcoords, sums, voxel, subj,
-                     labels, (long)V, (long)N, n_cls, class_w, scratch);
+  StepPrepareArgs a = {dcoords, (long)n_dcoords, sums, voxel, subj, labels, (long)V, (long)N, n_cls, class_w, scratch};
+  hipLaunchKernelGGL(k_step_prepare, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -799,22 +799,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_dout_prep(FinalBwdArgs a, T *dou
 // ----------------------------------------------------------------------------------------
 // packing: fp32 master weights -> zero-padded T copies (optionally transposed)
 // ----------------------------------------------------------------------------------------
-struct PackJob { const float *src; long dst; int rows, cols, ld, rowsP, colsP, transpose; };
+#include "step_device.h"
 #define PACK_MAX_JOBS 64
 struct PackArgs { PackJob job[PACK_MAX_JOBS]; int njobs; void *packed; };
 
 template <typename T>
-__global__ void k_pack(PackArgs a) {
-  const PackJob j = a.job[blockIdx.y];
-  T *dst = (T *)a.packed + j.dst;
-  const long total = (long)j.rowsP * j.colsP;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / j.colsP), cc = (int)(e - (long)r * j.colsP);
-    // destination element (r, cc) of a [rowsP x colsP] matrix; source is (r, cc) or (cc, r)
-    const int sr = j.transpose ? cc : r, sc = j.transpose ? r : cc;
-    const float v = (sr < j.rows && sc < j.cols) ? j.src[(size_t)sr * j.ld + sc] : 0.f;
-    dst[e] = (T)v;
-  }
+__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+  pack_job_body<T>(a.job[blockIdx.y], a.packed, blockIdx.x, gridDim.x);
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -8,6 +8,7 @@
 namespace {
 
 #include "k1_device.h"
+#include "step_device.h"
 
 
 __global__ void k_affine_from_embed(const float *embed, long rows, int dim, float *affine) {
@@ -84,21 +85,8 @@ __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const floa
   for (int k = 0; k < dim; ++k) dembed[n * dim + k] = g[k];
 }
 
-__global__ void k_node_major(const float *lat, long S, int C, int G, float *shadow) {
-  // (S, C, G) -> (S, G, C); one block per (subject, 32x32 tile) through LDS
-  __shared__ float tile[32][33];
-  const long s = blockIdx.z;
-  const int c0 = blockIdx.y * 32, g0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    const int c = c0 + r, g = g0 + tx;
-    tile[r][tx] = (c < C && g < G) ? lat[(s * C + c) * G + g] : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int g = g0 + r, c = c0 + tx;
-    if (g < G && c < C) shadow[(s * G + g) * C + c] = tile[tx][r];
-  }
+__global__ __launch_bounds__(256) void k_node_major(const float *lat, long S, int C, int G, float *shadow) {
+  node_major_body(lat, S, C, G, shadow, blockIdx.x);
 }
 
 
@@ -519,9 +507,9 @@ extern "C" int cinema_affine_from_embedding(const float *embed, int64_t rows, in
 
 extern "C" int cinema_latent_to_node_major(const float *latents, int64_t S, int32_t C, int32_t G, float *shadow, void *stream) {
   CINEMA_REQUIRE(latents && shadow && S >= 1 && C >= 1 && G >= 1, "cinema_latent_to_node_major: bad argument");
-  CINEMA_REQUIRE(S <= 65535, "too many subjects per rank (%ld > 65535)", (long)S);
-  dim3 grid((G + 31) / 32, (C + 31) / 32, (unsigned)S);
-  hipLaunchKernelGGL(k_node_major, grid, dim3(256), 0, (hipStream_t)stream, latents, (long)S, C, G, shadow);
+  const long nwg = (long)((G + 31) / 32) * ((C + 31) / 32) * S;
+  CINEMA_REQUIRE(nwg < (1L << 31), "latent table too large for one launch (%ld tiles)", nwg);
+  hipLaunchKernelGGL(k_node_major, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, latents, (long)S, C, G, shadow);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -240,17 +240,30 @@ def k1_forward_sorted(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor,
           "cinema_affine_trilerp_fwd_sorted")
 
 
-def step_head(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
-              cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
-    """eng.pack(1) + k1_forward_sorted in one launch (cinema_step_head); the caller checked k1_sorted_eligible and
-    eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use)."""
+def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
+              cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, prepare: Optional[dict] = None,
+              shadow: bool = True):
+    """eng.pack() + k1_forward_sorted (+ k1_shadow, + step_prepare) in ONE launch (cinema_step_head); the caller
+    checked k1_sorted_eligible and eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use).
+    prepare: dict(dcoords, sums, n_cls, class_w, voxel, labels, V, scratch) or None."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents.shape
     cond_dims = 0 if cond is None else cond.shape[1]
     npad = round_up(n, ROW_ALIGN)
+    sh = None
+    if shadow:
+        G = lx * ly * lz
+        if st.shadow is None or st.shadow.numel() != S * G * Cc:
+            st.shadow = torch.empty(S, G, Cc, device=eng.device, dtype=torch.float32)
+        sh = st.shadow
+    p = prepare or {}
+    dco = p.get("dcoords")
     check(lib.cinema_step_head(C.byref(d), ptr(eng.flat), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
                                0 if tfs is None else tfs.shape[1], ptr(latents), ptr(cond) if cond_dims else None, n, npad,
-                               S, Cc, lx, ly, lz, cond_dims, ptr(ws.coords_t), ptr(ws.lat), eng.stream()), "cinema_step_head")
+                               S, Cc, lx, ly, lz, cond_dims, ptr(ws.coords_t), ptr(ws.lat), ptr(sh), ptr(dco),
+                               0 if dco is None else dco.numel(), ptr(p.get("sums")), ptr(p.get("voxel")), ptr(p.get("labels")),
+                               int(p.get("V", 0)), int(p.get("n_cls", 0)), ptr(p.get("class_w")), ptr(p.get("scratch")),
+                               eng.stream()), "cinema_step_head")
 
 
 def k1_shadow(eng: SirenEngine, st: TrilerpState, latents: torch.Tensor):

@@ -179,13 +179,6 @@ class HotPathTrainer:
 
         one_head = fast_k1 and eng.can_skip_saved()      # grouped batch on the activation-stationary bf16 path
 
-        def head():                                   # forward half of the repacking + K1 forward
-            if one_head:
-                E.step_head(eng, coords, subj, self.latents.data, cond, tfs, n)      # ... as ONE launch
-            else:
-                eng.pack(1)
-                k1_fwd()
-
         def k1_fwd():
             if fast_k1:
                 E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
@@ -199,19 +192,27 @@ class HotPathTrainer:
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
                            self.prep_scratch)                     # cleared sums / dcoords + class-weight normaliser
 
-        if self.side is not None:
+        joined = True
+        if one_head:
+            # everything in front of the forward as ONE launch (cinema_step_head): no second stream, no join
+            E.step_head(eng, self.k1, coords, subj, self.latents.data, cond, tfs, n,
+                        prepare=dict(dcoords=ws.dcoords, sums=self.sums, n_cls=self.n_cls, class_w=self.class_w if use_cw else None,
+                                     voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch))
+        elif self.side is not None:
             side = self.side
             side.wait_stream(main)                  # the previous step's optimiser wrote the parameters
             with torch.cuda.stream(side):
                 backward_only_prep()                # nothing the forward reads: beside it, joined before the loss kernel
                 self.ev_prep.record(side)
-            head()                                  # what the forward reads stays on this stream (a cross-stream wait
-                                                    # costs 6-10 us of idle queue)
+            eng.pack(1)                             # what the forward reads stays on this stream (a cross-stream wait
+            k1_fwd()                                # costs 6-10 us of idle queue)
+            joined = False
         else:
-            head()
+            eng.pack(1)
+            k1_fwd()
             backward_only_prep()
         eng.forward(n)
-        if self.side is not None:
+        if not joined:
             main.wait_event(self.ev_prep)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,

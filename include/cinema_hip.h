@@ -160,14 +160,18 @@ int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, co
                                      int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t precision,
                                      float *coords_t, void *lat_out, int32_t LP, void *stream);
 
-/* The head of a training step in ONE launch: cinema_siren_pack_part(..., 1) and cinema_affine_trilerp_fwd_sorted as
- * block ranges of one kernel (independent work that separate launches on one stream would run one after the other).
- * bf16 stacks on the activation-stationary path only (hidden <= 512, `pk_fs >= 0` after planning) and the shapes
- * cinema_affine_trilerp_fwd_sorted takes; LP and the precision come from the descriptor.  Same bits as the two calls. */
+/* The head of a training step in ONE launch: cinema_siren_pack (both parts), cinema_affine_trilerp_fwd_sorted and,
+ * optionally, cinema_latent_to_node_major (shadow != NULL; only the K1 backward reads the shadow) and cinema_step_prepare
+ * (sums != NULL; subj = idx) as block ranges of one kernel -- independent work that separate launches would run one
+ * after the other on one stream, or with a 6-10 us join on two.  bf16 stacks on the activation-stationary path only
+ * (hidden <= 512, `pk_fs >= 0` after planning) and the shapes cinema_affine_trilerp_fwd_sorted takes; LP and the
+ * precision come from the descriptor.  Same bits as the separate calls. */
 int cinema_step_head(const cinema_siren_desc *d /* host */, const float *params, void *packed, const float *coords,
                      const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                      int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
-                     float *coords_t, void *lat_out, void *stream);
+                     float *coords_t, void *lat_out, float *shadow, float *dcoords, int64_t n_dcoords, float *sums,
+                     const int64_t *voxel, const uint8_t *labels, int64_t V, int32_t n_cls, const float *class_w,
+                     float *scratch, void *stream);
 
 /* Backward of the above:
  *   dlat [Npad x LP] fp32, dcoords_t [Npad x 3] fp32 (gradient reaching the registered

@@ -329,11 +329,12 @@ def test_epoch_walks_the_whole_list_and_steps_the_schedule():
     assert tr.epoch(n, generator=torch.Generator(device=DEV).manual_seed(4), max_steps=2) == 2
 
 
-def test_step_head_equals_pack_plus_sorted_forward():
-    """cinema_step_head (one launch) leaves the same bits as cinema_siren_pack_part(1) + cinema_affine_trilerp_fwd_sorted:
-    packed weight streams / side block / padded final_linear, registered coordinates, interpolated latent rows."""
+def test_step_head_equals_the_separate_launches():
+    """cinema_step_head (one launch) leaves the same bits as cinema_siren_pack + cinema_affine_trilerp_fwd_sorted +
+    cinema_latent_to_node_major + cinema_step_prepare: packed weight copies, registered coordinates, interpolated latent
+    rows, node-major shadow, cleared dcoords and the loss sums with the class-weight normaliser."""
     from cinema_amd import _lib, engine as E
-    S, Cc, n = 9, 64, 3000 + 11
+    S, Cc, n, V = 9, 64, 3000 + 11, 4096
     d = E.make_desc(3, Cc, 12, 256, 4, [1, 3], 30, 30, _lib.PREC_BF16)
     eng = E.SirenEngine(d, DEV)
     assert eng.can_skip_saved()
@@ -343,17 +344,32 @@ def test_step_head_equals_pack_plus_sorted_forward():
     tfs = ((torch.rand(S, 6, generator=g) - 0.5) * 0.2).to(DEV)
     coords = (torch.rand(n, 3, generator=g) * 2.2 - 1.1).to(DEV)
     idx = torch.randint(0, S, (n,), generator=g, dtype=torch.int32).sort().values.to(DEV)
+    voxel = torch.randint(0, V, (n,), generator=g, dtype=torch.int64).to(DEV)
+    labels = torch.randint(0, 10, (S * V,), generator=g, dtype=torch.uint8).to(DEV)
+    class_w = (torch.rand(10, generator=g) + 0.5).to(DEV)
     ws = eng.workspace(n)
+    ws.ensure_backward()
     npad = E.round_up(n, 128)
+    st_a, st_b = E.TrilerpState(), E.TrilerpState()
+    sums_a, sums_b = torch.full((4,), 7.0, device=DEV), torch.full((4,), 7.0, device=DEV)
+    scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=DEV)
     eng.packed.zero_()
-    eng.pack(1)
-    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
+    eng.pack()
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan")); ws.dcoords.fill_(3.0)
     E.k1_forward_sorted(eng, coords, idx, latents, None, tfs, n)
-    ref = (eng.packed.clone(), ws.coords_t[:npad].clone(), ws.lat[:npad].clone())
+    E.k1_shadow(eng, st_a, latents)
+    E.step_prepare(ws.dcoords, sums_a, n, 10, class_w, voxel, idx, labels, V, scratch)
+    ref = (eng.packed.clone(), ws.coords_t[:npad].clone(), ws.lat[:npad].clone(), ws.dcoords.clone())
     eng.packed.zero_()
-    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan"))
-    E.step_head(eng, coords, idx, latents, None, tfs, n)
+    ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan")); ws.dcoords.fill_(3.0)
+    E.step_head(eng, st_b, coords, idx, latents, None, tfs, n,
+                prepare=dict(dcoords=ws.dcoords, sums=sums_b, n_cls=10, class_w=class_w, voxel=voxel, labels=labels, V=V,
+                             scratch=scratch))
     torch.cuda.synchronize()
     assert torch.equal(eng.packed.view(torch.int16), ref[0].view(torch.int16))
     assert torch.equal(ws.coords_t[:npad].view(torch.int32), ref[1].view(torch.int32))
     assert torch.equal(ws.lat[:npad].view(torch.int16), ref[2].view(torch.int16))
+    assert torch.equal(ws.dcoords, ref[3]) and float(ws.dcoords.abs().max()) == 0.0
+    assert torch.equal(st_a.shadow, st_b.shadow)
+    assert torch.equal(sums_a, sums_b) and float(sums_a[2]) > 0 and float(sums_a[0]) == 0.0
+    assert float(scratch[256:].abs().max()) == 0.0          # the arrival counter was reset
