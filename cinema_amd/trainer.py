@@ -141,16 +141,10 @@ class HotPathTrainer:
                 if opt is not None:
                     self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
         self.sums = torch.zeros(4, device=self.device)
-        # second stream: the weight repacking runs beside the latent gather (independent work the one-stream order would
-        # serialise).  The weight-gradient GEMMs beside the latent-side backward were tried the same way and gain
-        # nothing: k_dw256 holds 128 KB of LDS and 432 of 512 registers per SIMD on 245 CUs, the latent-side kernels
-        # cannot become resident next to it and crawl on the remaining CUs (profiles/r01_two_stream_note.txt)
-        # The same stream carries the per-step clearing (registered-coordinate gradient, loss sums) and the class-weight
-        # normaliser of the batch, none of which depends on the forward; the optimiser leaves the gradients zeroed.
-        # Together: four fills and the class-weight pre-pass (25 us) leave the critical path of a step.
-        # One process of several (world > 1) keeps everything on ONE stream for now: the collective library brings its
-        # own streams, the two-event choreography above has not run next to RCCL on a real node yet, and the 35 us it
-        # saves per step are not worth risking a stalled job in the round's only multi-GPU run.
+        # Grouped batches on the bf16 chain kernels need no second stream: everything in front of the forward is ONE
+        # launch (cinema_step_head).  The fallback shapes keep the backward-only preparation (transposed linear_lats copies,
+        # node-major shadow, per-step clearing + class-weight normaliser) on a side stream that joins before the loss
+        # kernel; a rank of several keeps one stream there too (the collective library brings its own).
         self.side = torch.cuda.Stream(device=self.device) if self.world == 1 else None
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_prep = torch.cuda.Event()
