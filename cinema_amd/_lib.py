@@ -14,6 +14,7 @@ PREC_F32, PREC_BF16 = 0, 1
 BWD_SKIP_WEIGHT_GRADS = 1
 BWD_GRADS_CLEARED, BWD_DCOORDS_CLEARED = 2, 64
 PREPARE_SCRATCH = 260
+PENDING_BYTES = 4096
 BWD_PHASE_CHAIN, BWD_PHASE_DLAT, BWD_PHASE_DW, BWD_PHASE_FINAL_DW = 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +54,7 @@ SIGNATURES = {
     "cinema_siren_pack_part": [C.POINTER(SirenDesc), _P, _P, _I32, _P],
     "cinema_siren_forward": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I64, _I64, _P, _P, _P],
     "cinema_siren_backward": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I32, _P],
+    "cinema_siren_backward_deferred": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I32, _P, _P],
     "cinema_affine_from_embedding": [_P, _I64, _I32, _P, _P],
     "cinema_latent_to_node_major": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_affine_trilerp_fwd": [_P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P,
@@ -65,6 +67,8 @@ SIGNATURES = {
                                   _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_sorted": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                          _I32, _I32, _P, _P, _P, _P, _P],
+    "cinema_affine_trilerp_bwd_sorted_pending": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32,
+                                                 _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],

@@ -328,12 +328,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
 // ----------------------------------------------------------------------------------------
 // grouped weight-gradient GEMMs: dW[h][k] += sum_n P[n][h] * Q[n][k]
 // ----------------------------------------------------------------------------------------
-struct DwProb { const void *P; const void *Q; float *out; int ldp, ldq, ldo, M, K, tk; };
-struct DwArgs {
-  DwProb p[3 * CINEMA_MAX_LAYERS + 2];
-  int tile_start[3 * CINEMA_MAX_LAYERS + 3];
-  int nprob, splitk, Npad;
-};
+#include "dw_device.h"
 
 template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
@@ -393,7 +388,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
 #define DW256_SMEM (DW256_NBUF * 2 * DW256_TILE)  // 128 KB
 #define DW256_MAX_SPLIT 8
 
-struct Dw256Args { DwArgs g; float *slab; };
 typedef __attribute__((address_space(1))) const void gmem_cvoid;
 
 __device__ __forceinline__ int dw256_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -678,28 +672,7 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   }
 }
 
-// out[h][k] = sum over the splits of one tile; block = 8 rows of one tile, thread = 8 columns
-__global__ __launch_bounds__(256) void k_dw256_reduce(Dw256Args a) {
-  const int tg = blockIdx.x >> 5, rb = blockIdx.x & 31;
-  int pi = 0;
-  while (pi + 1 < a.g.nprob && tg >= a.g.tile_start[pi + 1]) ++pi;
-  const DwProb pr = a.g.p[pi];
-  const int t = tg - a.g.tile_start[pi];
-  const int h0 = (t / pr.tk) * 256, c0 = (t % pr.tk) * 256;
-  const int row = rb * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 8;
-  if (h0 + row >= pr.M || c0 + col >= pr.K) return;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  const float *src = a.slab + (size_t)tg * a.g.splitk * (256 * 256) + row * 256 + col;
-  for (int sp = 0; sp < a.g.splitk; ++sp) {
-    s0 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256));
-    s1 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256) + 4);
-  }
-  float *out = pr.out + (size_t)(h0 + row) * pr.ldo + c0 + col;
-  const int nv = pr.K - c0 - col;
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (j < nv) out[j] = j < 4 ? s0[j & 3] : s1[j & 3];
-}
+__global__ __launch_bounds__(256) void k_dw256_reduce(Dw256Args a) { dw256_reduce_body(a, (int)blockIdx.x); }
 
 // ----------------------------------------------------------------------------------------
 // final linear (siren.py:61):  out[n][o] = bf[o] + sum_k [x_L | lat][n][k] * Wf[o][k]
@@ -1077,7 +1050,10 @@ static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
 template <typename T>
 static int backward_impl(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                          const void *lat, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
-                         float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s) {
+                         float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s, Dw256Args *pending = nullptr) {
+  // pending != NULL: the split reduction of the 256 x 256 weight-gradient tiles is NOT launched; its arguments go to
+  // *pending for the caller to run (cinema_affine_trilerp_bwd_sorted_pending: beside the K1 coordinate gradient)
+  if (pending) { pending->g.nprob = 0; pending->slab = nullptr; }
   const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP, nl = d->n_layers;
   const bool wgrads = !(flags & CINEMA_BWD_SKIP_WEIGHT_GRADS);
   const int phases = (flags & CINEMA_BWD_PHASE_MASK) ? (flags & CINEMA_BWD_PHASE_MASK) : CINEMA_BWD_PHASE_MASK;
@@ -1248,8 +1224,12 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
         }
         hipLaunchKernelGGL(k_dw256, dim3(t256 * sk), dim3(DW256_THREADS), DW256_SMEM, s, b);
         CINEMA_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_dw256_reduce, dim3(t256 * 32), dim3(256), 0, s, b);
-        CINEMA_CHECK_HIP(hipGetLastError());
+        if (pending) {
+          *pending = b;
+        } else {
+          hipLaunchKernelGGL(k_dw256_reduce, dim3(t256 * 32), dim3(256), 0, s, b);
+          CINEMA_CHECK_HIP(hipGetLastError());
+        }
         (void)N;
         return 0;
       }
@@ -1285,4 +1265,21 @@ extern "C" int cinema_siren_backward(const cinema_siren_desc *d, const float *pa
                                      dcoords, flags, s)
              : backward_impl<float>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
                                     dcoords, flags, s);
+}
+
+extern "C" int cinema_siren_backward_deferred(const cinema_siren_desc *d, const float *params, const void *packed,
+                                              const float *coords_t, const void *lat, const void *saved, const float *dout,
+                                              int64_t N, int64_t Npad, void *gbuf, float *grad_params, float *dlat,
+                                              float *dcoords, int32_t flags, void *pending, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && saved && dout && gbuf && dlat && dcoords && pending,
+                 "cinema_siren_backward_deferred: null argument");
+  CINEMA_REQUIRE((flags & CINEMA_BWD_SKIP_WEIGHT_GRADS) || grad_params, "cinema_siren_backward: grad_params is null");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0, "cinema_siren_backward: need 1 <= N <= Npad, Npad %% 128 == 0");
+  static_assert(sizeof(Dw256Args) <= CINEMA_PENDING_BYTES, "CINEMA_PENDING_BYTES too small");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16
+             ? backward_impl<bf16_t>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
+                                     dcoords, flags, s, (Dw256Args *)pending)
+             : backward_impl<float>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
+                                    dcoords, flags, s, (Dw256Args *)pending);
 }

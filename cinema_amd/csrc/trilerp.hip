@@ -9,6 +9,7 @@ namespace {
 
 #include "k1_device.h"
 #include "step_device.h"
+#include "dw_device.h"
 
 
 __global__ void k_affine_from_embed(const float *embed, long rows, int dim, float *affine) {
@@ -137,12 +138,12 @@ struct TriBwdArgs {
   int32_t *sorted_offsets;   // non-NULL: idx is non-decreasing, write offsets[0..S] (first sample of every subject)
 };
 
-__global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
+__device__ __forceinline__ void trilerp_bwd_coord_body(const TriBwdArgs &a, const unsigned vbid, const unsigned vgrid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int G = a.lx * a.ly * a.lz;
   if (a.sorted_offsets != nullptr) {
     // batch already grouped by subject: the per-subject ranges are a lower_bound per subject (no counting sort)
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t <= a.S; t += (long)gridDim.x * blockDim.x) {
+    for (long t = (long)vbid * 256 + threadIdx.x; t <= a.S; t += (long)vgrid * 256) {
       long lo = 0, hi = a.N;
       while (lo < hi) {
         const long mid = (lo + hi) >> 1;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
       a.sorted_offsets[t] = (int32_t)(t == a.S ? a.N : lo);
     }
   }
-  for (long n = (long)blockIdx.x * 4 + wave; n < a.N; n += (long)gridDim.x * 4) {
+  for (long n = (long)vbid * 4 + wave; n < a.N; n += (long)vgrid * 4) {
     const float t0 = a.coords_t[n * 3], t1 = a.coords_t[n * 3 + 1], t2 = a.coords_t[n * 3 + 2];
     long s = a.idx[n];
     s = s < 0 ? 0 : (s >= a.S ? a.S - 1 : s);
@@ -197,6 +198,16 @@ __global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) {
     if (a.dcond != nullptr)
       for (int j = lane; j < a.cond_dims; j += 64) a.dcond[n * a.cond_dims + j] = grow[a.C + j];
   }
+}
+
+__global__ __launch_bounds__(256) void k_trilerp_bwd_coord(TriBwdArgs a) { trilerp_bwd_coord_body(a, blockIdx.x, gridDim.x); }
+
+// The coordinate gradient and the split reduction of the weight-gradient tiles (k_dw256's slabs -> flat gradient) are
+// independent and both short: as block ranges of one launch they overlap (29 + 16 us in a row otherwise).
+__global__ __launch_bounds__(256) void k_bwd_coord_reduce(TriBwdArgs a, Dw256Args r, int g_coord, int g_red) {
+  const int b = blockIdx.x;                      // workgroup-uniform; the streaming job first, the latency-bound one fills in
+  if (b < g_red) dw256_reduce_body(r, b);
+  else trilerp_bwd_coord_body(a, b - g_red, g_coord);
 }
 
 // ---- grouping of the samples by subject (counting sort) ----
@@ -559,7 +570,7 @@ static int trilerp_bwd_impl(bool sorted, const float *coords, const int32_t *idx
                             int32_t embed_per_sample, const float *affine, const float *shadow, const float *coords_t,
                             const float *dlat, float *dcoords_t, int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx,
                             int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP, float *dlatents, float *dembed,
-                            float *dcond, int32_t *work, void *stream) {
+                            float *dcond, int32_t *work, void *stream, const Dw256Args *pending = nullptr) {
   (void)affine; (void)Npad;
   CINEMA_REQUIRE(coords && idx && coords_t && dcoords_t, "cinema_affine_trilerp_bwd: null argument");
   CINEMA_REQUIRE(dlat == nullptr || (shadow && work), "cinema_affine_trilerp_bwd: dlat given without shadow/work");
@@ -571,7 +582,16 @@ static int trilerp_bwd_impl(bool sorted, const float *coords, const int32_t *idx
     TriBwdArgs a = {idx, shadow, coords_t, dlat, (long)N, (long)S, C, lx, ly, lz, cond_dims, LP, dcoords_t, dcond,
                     sorted ? work + S : nullptr};
     const unsigned grid = (unsigned)std::min<long>((N + 3) / 4, 8192);
-    hipLaunchKernelGGL(k_trilerp_bwd_coord, dim3(grid), dim3(256), 0, s, a);
+    if (pending != nullptr && pending->g.nprob > 0) {
+      const int t256 = pending->g.tile_start[pending->g.nprob];
+      hipLaunchKernelGGL(k_bwd_coord_reduce, dim3(grid + 32u * t256), dim3(256), 0, s, a, *pending, (int)grid, 32 * t256);
+    } else {
+      hipLaunchKernelGGL(k_trilerp_bwd_coord, dim3(grid), dim3(256), 0, s, a);
+    }
+    CINEMA_CHECK_HIP(hipGetLastError());
+  } else if (pending != nullptr && pending->g.nprob > 0) {
+    hipLaunchKernelGGL(k_bwd_coord_reduce, dim3(32u * pending->g.tile_start[pending->g.nprob]), dim3(256), 0, s, TriBwdArgs{}, *pending, 0,
+                       32 * pending->g.tile_start[pending->g.nprob]);
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   const bool table_tf = dembed != nullptr && !embed_per_sample;
@@ -639,4 +659,17 @@ extern "C" int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32
                                                 int32_t *work, void *stream) {
   return trilerp_bwd_impl(true, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
                           Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream);
+}
+
+extern "C" int cinema_affine_trilerp_bwd_sorted_pending(const float *coords, const int32_t *idx, const float *embed,
+                                                        int32_t tf_dim, int32_t embed_per_sample, const float *affine,
+                                                        const float *shadow, const float *coords_t, const float *dlat,
+                                                        float *dcoords_t, int64_t N, int64_t Npad, int64_t S, int32_t C,
+                                                        int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                                                        float *dlatents, float *dembed, float *dcond, int32_t *work,
+                                                        const void *pending, void *stream) {
+  CINEMA_REQUIRE(pending != nullptr, "cinema_affine_trilerp_bwd_sorted_pending: pending is null");
+  return trilerp_bwd_impl(true, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
+                          Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream,
+                          (const Dw256Args *)pending);
 }

@@ -160,7 +160,7 @@ class SirenEngine:
         return ws.out
 
     def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0,
-                 dcoords_cleared: bool = False):
+                 dcoords_cleared: bool = False, pending=None):
         """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords.
         dcoords_cleared: ws.dcoords already holds zeros (step_prepare); flat_grad is not cleared again when a
         clearing optimiser step left it zeroed (grads_clean)."""
@@ -174,6 +174,15 @@ class SirenEngine:
             if self.grads_clean and phases == 0:
                 flags |= _lib.BWD_GRADS_CLEARED
             self.grads_clean = False
+        if pending is not None:
+            # the split reduction of the weight-gradient tiles is left to the caller (k1_backward(pending=...) runs it
+            # beside the K1 coordinate gradient): flat_grad is complete only after that call
+            check(self.lib.cinema_siren_backward_deferred(C.byref(self.desc), ptr(self.flat), ptr(self.packed),
+                                                          ptr(ws.coords_t), ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n,
+                                                          npad, ptr(ws.gbuf), ptr(self.flat_grad), ptr(ws.dlat),
+                                                          ptr(ws.dcoords), flags, C.byref(pending), self.stream()),
+                  "cinema_siren_backward_deferred")
+            return
         check(self.lib.cinema_siren_backward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
                                              ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n, npad, ptr(ws.gbuf),
                                              ptr(self.flat_grad), ptr(ws.dlat), ptr(ws.dcoords), flags, self.stream()),
@@ -279,7 +288,7 @@ def k1_shadow(eng: SirenEngine, st: TrilerpState, latents: torch.Tensor):
 def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
                 cond_dims: int, tfs: Optional[torch.Tensor], tf_per_sample: bool, n: int,
                 want_latents: bool = True, want_cond: bool = False, dtf_out: Optional[torch.Tensor] = None,
-                dlat_out: Optional[torch.Tensor] = None, grouped: bool = False):
+                dlat_out: Optional[torch.Tensor] = None, grouped: bool = False, pending=None):
     """Returns (dlatents | None, dtfs | None, dcond | None) from eng.ws.dlat / eng.ws.dcoords.
     grouped=True: the caller guarantees idx is non-decreasing (batch sorted by subject)."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
@@ -301,13 +310,18 @@ def k1_backward(eng: SirenEngine, st: TrilerpState, coords: torch.Tensor, idx: t
             dtfs = torch.zeros(tfs.shape[0], tfs.shape[1], device=eng.device, dtype=torch.float32)
     dcond = torch.empty(n, cond_dims, device=eng.device, dtype=torch.float32) if (want_cond and cond_dims) else None
     npad = round_up(n, ROW_ALIGN)
-    fn = lib.cinema_affine_trilerp_bwd_sorted if grouped else lib.cinema_affine_trilerp_bwd
-    check(fn(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
-                                        1 if tf_per_sample else 0, ptr(st.affine) if tfs is not None else None,
-                                        ptr(st.shadow), ptr(ws.coords_t), ptr(ws.dlat), ptr(ws.dcoords), n, npad, S, Cc,
-                                        lx, ly, lz, cond_dims, d.LP, ptr(dlatents), ptr(dtfs), ptr(dcond), ptr(st.work),
-                                        eng.stream()),
-          "cinema_affine_trilerp_bwd")
+    args = (ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1], 1 if tf_per_sample else 0,
+            ptr(st.affine) if (tfs is not None and st.affine is not None) else None, ptr(st.shadow), ptr(ws.coords_t),
+            ptr(ws.dlat), ptr(ws.dcoords), n, npad, S, Cc, lx, ly, lz, cond_dims, d.LP, ptr(dlatents), ptr(dtfs), ptr(dcond),
+            ptr(st.work))
+    if pending is not None:
+        if not grouped:
+            raise ValueError("k1_backward: a pending weight-gradient reduction rides with the grouped entry point only")
+        check(lib.cinema_affine_trilerp_bwd_sorted_pending(*args, C.byref(pending), eng.stream()),
+              "cinema_affine_trilerp_bwd_sorted_pending")
+    else:
+        fn = lib.cinema_affine_trilerp_bwd_sorted if grouped else lib.cinema_affine_trilerp_bwd
+        check(fn(*args, eng.stream()), "cinema_affine_trilerp_bwd")
     return dlatents, dtfs, dcond
 
 

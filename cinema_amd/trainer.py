@@ -12,6 +12,7 @@ K1 bwd -> optimiser.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -148,6 +149,7 @@ class HotPathTrainer:
         self.side = torch.cuda.Stream(device=self.device) if self.world == 1 else None
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_prep = torch.cuda.Event()
+        self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -211,7 +213,10 @@ class HotPathTrainer:
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
                       labels=st.labels, voxels_per_subject=st.V, prepared=True)
-        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True)
+        # one rank: nobody needs the flat gradient before the optimiser, so the split reduction of the weight-gradient
+        # tiles rides with the K1 backward's first launch (beside the coordinate gradient) instead of a launch of its own
+        pending = self.pending if (grouped and self.train_mlp and self.world == 1) else None
+        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, pending=pending)
         work = None
         if self.train_mlp and self.world > 1:
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
@@ -219,7 +224,7 @@ class HotPathTrainer:
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
                                     want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
-                                    dlat_out=self.lat_grad, grouped=grouped)
+                                    dlat_out=self.lat_grad, grouped=grouped, pending=pending)
         if want_tf and self.tf_weight != 0.0:
             self._add_tf_regulariser_grad(subj, n)
         self.latents.grad = self.lat_grad

@@ -196,6 +196,23 @@ int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32_t *idx, co
                                      int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
                                      float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream);
 
+/* cinema_siren_backward for a training loop that runs the split reduction of the weight-gradient tiles elsewhere: the
+ * reduction's arguments are written to `pending` (HOST memory, CINEMA_PENDING_BYTES, opaque) instead of being launched;
+ * grad_params holds the bias / first-layer / final-bias gradients only until the pending reduction has run
+ * (cinema_affine_trilerp_bwd_sorted_pending runs it as a block range beside the K1 coordinate gradient, which is
+ * independent of it).  Nothing is pending on the paths without split tiles (fp32, hidden < 256, Npad < 4096). */
+#define CINEMA_PENDING_BYTES 4096
+int cinema_siren_backward_deferred(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                                   const float *coords_t, const void *lat, const void *saved, const float *dout, int64_t N,
+                                   int64_t Npad, void *gbuf, float *grad_params, float *dlat, float *dcoords, int32_t flags,
+                                   void *pending /* host */, void *stream);
+int cinema_affine_trilerp_bwd_sorted_pending(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                             int32_t embed_per_sample, const float *affine, const float *shadow,
+                                             const float *coords_t, const float *dlat, float *dcoords_t, int64_t N,
+                                             int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                                             int32_t cond_dims, int32_t LP, float *dlatents, float *dembed, float *dcond,
+                                             int32_t *work, const void *pending /* host */, void *stream);
+
 /* -------------------------------------------------------------------------------------
  * K3: ground-truth sampling + loss + dLoss/dOutput (Criterion.forward, utils.py:88-104,
  * and the integer gather `vol[c_nz]` of data_loading/dataset.py:87-89).
