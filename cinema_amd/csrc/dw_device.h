@@ -34,3 +34,39 @@ __device__ __forceinline__ void dw256_reduce_body(const Dw256Args &a, int vbid) 
   for (int j = 0; j < 8; ++j)
     if (j < nv) out[j] = j < 4 ? s0[j & 3] : s1[j & 3];
 }
+
+// dOut [Npad x out_dim] fp32 -> [Npad x 16] T (zero padded) so that the final_linear weight gradient joins the grouped
+// weight-gradient launch as two more problems (P = dOut16, Q = x_L and Q = lat); also reduces the bias gradient.
+// Any workgroup size that is a multiple of 64 up to 512; vbid / vgrid as in step_device.h.
+struct FinalBwdArgs { const float *dout; int out_dim; float *dbf; int Npad; };
+template <typename T>
+__device__ __forceinline__ void dout_prep_body(const FinalBwdArgs &a, T *dout16, unsigned vbid, unsigned vgrid) {
+  __shared__ float red[8][16];
+  const int nthr = blockDim.x;
+  float colsum[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) colsum[o] = 0.f;
+  for (int n = vbid * nthr + threadIdx.x; n < a.Npad; n += vgrid * nthr) {
+    float v[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      v[o] = o < a.out_dim ? a.dout[(size_t)n * a.out_dim + o] : 0.f;
+      colsum[o] += v[o];
+    }
+    store16(dout16 + (size_t)n * 16, v);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = nthr >> 6;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float s = colsum[o];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) red[wave][o] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.out_dim && a.dbf != nullptr) {
+    float t = 0.f;
+    for (int w = 0; w < nwave; ++w) t += red[w][threadIdx.x];
+    atomicAdd(a.dbf + threadIdx.x, t);
+  }
+}

@@ -20,4 +20,4 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
                   const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s);
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
-                         hipStream_t s);
+                         hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr);

@@ -16,6 +16,7 @@ namespace {
 
 #include "k1_device.h"
 #include "step_device.h"
+#include "dw_device.h"
 
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
 inline int ksteps(int k) { return round_up_i(k / 32, FUSED_RING); }   // k32 steps of a segment, padded to the ring
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
 // GEMMs, reduces the bias gradients and leaves dz in LDS as the next g.
 // ----------------------------------------------------------------------------------------
 struct FusedBwdArgs {
+  FinalBwdArgs fin; bf16_t *dout16; int g_chain, g_fin;   // tail workgroups: dOut -> [Npad x 16] bf16 + final bias gradient
   int g4;                            // workgroups [0, g4) own 64 samples, the rest 48 (fused_launch_plan)
   const bf16_t *stream; long slab_elems;
   const float *side_w0;              // [HP][4] first-layer weights, then [16][HP] final_linear.weight[:, :H]
@@ -674,6 +676,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long
 }
 
 __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
+  // behind the chain workgroups: the dOut preparation of the weight-gradient launch (reads dOut only; these workgroups
+  // land on the CUs the shorter second round leaves idle)
+  if ((int)blockIdx.x >= a.g_chain) { dout_prep_body<bf16_t>(a.fin, a.dout16, blockIdx.x - a.g_chain, a.g_fin); return; }
   if ((int)blockIdx.x < a.g4) fused_bwd_body<4>(a, 64L * blockIdx.x);
   else fused_bwd_body<3>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
@@ -886,7 +891,7 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
 
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *gp, float *dcoords, bool wgrads,
-                         hipStream_t s) {
+                         hipStream_t s, void *dout16, float *dbf) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_bs >= 0, "fused_backward_chain: descriptor not planned for the fused path");
   CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_backward_chain: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
   FusedBwdArgs a = {};
@@ -914,7 +919,13 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
   }
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
-  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+  a.g_chain = a.g4 + g3;
+  if (dout16 != nullptr) {
+    a.fin = FinalBwdArgs{dout, d->out_dim, dbf, (int)Npad};
+    a.dout16 = (bf16_t *)dout16;
+    a.g_fin = (int)std::min<int64_t>((Npad + 511) / 512, 128);
+  }
+  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

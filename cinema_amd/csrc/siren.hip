@@ -737,36 +737,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_final_fwd(FinalFwdArgs a) {
   }
 }
 
-struct FinalBwdArgs { const float *dout; int out_dim; float *dbf; int Npad; };
-
-// dOut [Npad x out_dim] fp32 -> [Npad x 16] T (zero padded) so that the final_linear weight gradient joins the
-// grouped TN launch as two more problems (P = dOut16, Q = x_L and Q = lat); also reduces the bias gradient.
 template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void k_dout_prep(FinalBwdArgs a, T *dout16) {
-  __shared__ float red[4][16];
-  float colsum[16];
-#pragma unroll
-  for (int o = 0; o < 16; ++o) colsum[o] = 0.f;
-  for (int n = blockIdx.x * WG_THREADS + threadIdx.x; n < a.Npad; n += gridDim.x * WG_THREADS) {
-    float v[16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      v[o] = o < a.out_dim ? a.dout[(size_t)n * a.out_dim + o] : 0.f;
-      colsum[o] += v[o];
-    }
-    store16(dout16 + (size_t)n * 16, v);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    float s = colsum[o];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) red[wave][o] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < a.out_dim && a.dbf != nullptr)
-    atomicAdd(a.dbf + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  dout_prep_body<T>(a, dout16, blockIdx.x, gridDim.x);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1071,8 +1044,17 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
 
   // ---- chain ----
   const bool fused_chain = std::is_same<T, bf16_t>::value && fused_mode(d) == 64;
+  bool dout_prep_done = false;
   if (fused_chain && (phases & CINEMA_BWD_PHASE_CHAIN))
-    if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s)) return rc;
+  {
+    // with weight gradients the dOut preparation rides as tail workgroups of the chain launch (it only reads dOut)
+    const bool prep_rides = wgrads && all_phases;
+    if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s,
+                                      prep_rides ? (void *)(gb + slot * (d->n_gbuf - 1)) : nullptr,
+                                      prep_rides ? gp + d->off_bf : nullptr))
+      return rc;
+    dout_prep_done = prep_rides;
+  }
   for (int i = nl - 1; i >= 0 && (phases & CINEMA_BWD_PHASE_CHAIN) && !fused_chain; --i) {
     const bool mod = (d->modulated_mask >> i) & 1u;
     const bool top = i == nl - 1, first = i == 0;
@@ -1159,7 +1141,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
 
   // ---- final_linear: dOut -> [Npad x 16] T copy (operand of the grouped launch) + bias gradient ----
   T *dout16 = gb + slot * (d->n_gbuf - 1);
-  if (phases & CINEMA_BWD_PHASE_FINAL_DW) {
+  if ((phases & CINEMA_BWD_PHASE_FINAL_DW) && !dout_prep_done) {
     FinalBwdArgs a = {};
     a.dout = dout; a.out_dim = d->out_dim; a.dbf = all_phases ? gp + d->off_bf : nullptr; a.Npad = (int)Npad;
     const int grid_f = (int)std::min<int64_t>((Npad + WG_THREADS - 1) / WG_THREADS, 256);
