@@ -118,12 +118,30 @@ def main():
                          "(checks the rank logic; the number it prints is not a result)")
     opt = ap.parse_args()
 
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, through the same
+        # launcher the driver uses.  This parent has made no GPU call (importing torch makes none); it only waits for the
+        # launcher and hands its exit status on -- a failed rank fails the run.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if opt.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {opt.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {opt.gpus})")
+    if not opt.rehearse_on_one_gpu and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s); one process per GPU "
+                         "(--rehearse-on-one-gpu runs the rank logic over gloo on one card)")
     if opt.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -133,8 +151,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    if opt.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {opt.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
     args = make_args(512, opt.precision, opt.loss, opt.n_samples)

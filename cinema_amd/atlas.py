@@ -49,7 +49,7 @@ def mean_latent(args: dict, latents: torch.Tensor, condition_values: torch.Tenso
     w_mine = (w_mine / total)[:, None, None, None, None]
     part = torch.sum(latents.detach() * w_mine, dim=0, keepdim=True)
     if world > 1:
-        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=process_group)
+        part = par.allreduce_sum(part, process_group)
     return part
 
 

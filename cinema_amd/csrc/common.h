@@ -13,6 +13,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 void cinema_set_error(const char *fmt, ...);
 
+// Launch state that belongs to a DEVICE (the dynamic-LDS limit hipFuncSetAttribute raises applies to the current device
+// only; CU counts differ between devices) is cached per device index, in relaxed atomics: any host thread may call.
+#include <atomic>
+#define CINEMA_MAX_DEVICES 64
+int cinema_dev();        // hipGetDevice(), clamped to [0, CINEMA_MAX_DEVICES)
+int cinema_cu_count();   // compute units of the current device (256 if the query fails)
+
 #define CINEMA_CHECK_HIP(expr)                                                              \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
@@ -20,6 +27,18 @@ void cinema_set_error(const char *fmt, ...);
       cinema_set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); \
       return (int)e_;                                                                       \
     }                                                                                       \
+  } while (0)
+
+// raise the dynamic-LDS limit of kernel `fn` to `bytes` on the current device (once per device and size)
+#define CINEMA_SMEM_ATTR(fn, bytes)                                                                        \
+  do {                                                                                                     \
+    static std::atomic<int> done_[CINEMA_MAX_DEVICES];                                                     \
+    const int dv_ = cinema_dev();                                                                          \
+    if (done_[dv_].load(std::memory_order_relaxed) < (int)(bytes)) {                                       \
+      CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)(bytes)));                                                 \
+      done_[dv_].store((int)(bytes), std::memory_order_relaxed);                                           \
+    }                                                                                                      \
   } while (0)
 
 #define CINEMA_REQUIRE(cond, ...)        \

@@ -833,13 +833,8 @@ extern "C" int cinema_debug_fused_trace(int block, int wave, long long *host_out
 // HBM at once -- where the mixed launch lets early finishers start the short tiles.  A delayed start of every other
 // workgroup, meant to desynchronise the phases, changed nothing.)  CINEMA_FUSED_SPLIT=0 keeps 64-sample tiles only.
 static void fused_launch_plan(int64_t Npad, int *g4, int *g3) {
-  static int ncu = 0;
   static const bool enabled = [] { const char *e = getenv("CINEMA_FUSED_SPLIT"); return !(e && e[0] == '0'); }();
-  if (!ncu) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      ncu = 256;
-  }
+  const int ncu = cinema_cu_count();
   const long units = Npad / 16;                      // Npad is a multiple of 64
   *g4 = (int)(units / 4); *g3 = 0;
   if (!enabled || units <= 4L * ncu) return;
@@ -876,11 +871,7 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   a.xsteps = ksteps(d->HP); a.lsteps = ksteps(d->LP);
   a.xrow = 64 * a.xsteps; a.lrow = 64 * a.lsteps;
   const int smem = fused_lds_bytes(d);
-  static int attr_smem = 0;
-  if (smem > attr_smem) {
-    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_smem = smem;
-  }
+  CINEMA_SMEM_ATTR(k_fused_fwd, smem);
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
   hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
@@ -912,11 +903,7 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
   a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
   const int smem = FUSED_TS * a.xrow + 20 * d->HP * 4 + FUSED_TS * 64 + FUSED_TS * 16;
   CINEMA_REQUIRE(smem <= 160 * 1024, "fused_backward_chain: LDS budget exceeded (%d bytes)", smem);
-  static int attr_smem = 0;
-  if (smem > attr_smem) {
-    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_smem = smem;
-  }
+  CINEMA_SMEM_ATTR(k_fused_bwd, smem);
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
   a.g_chain = a.g4 + g3;

@@ -756,14 +756,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-template <typename T>
-int set_smem_attr(const void *fn, int bytes) {
-  if (bytes > 48 * 1024) {
-    CINEMA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  }
-  return 0;
-}
-
 }  // namespace
 
 // ========================================================================================
@@ -920,11 +912,7 @@ extern "C" int cinema_siren_pack(const cinema_siren_desc *d, const float *params
 template <typename T, bool MOD, bool SMALLK>
 static int launch_fwd(const FwdArgs &a, int grid, hipStream_t s) {
   constexpr int smem = Engine<T>::NT_SMEM;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (int rc = set_smem_attr<T>((const void *)k_layer_fwd<T, MOD, SMALLK>, smem)) return rc;
-    attr_done = true;
-  }
+  CINEMA_SMEM_ATTR((k_layer_fwd<T, MOD, SMALLK>), smem);
   hipLaunchKernelGGL((k_layer_fwd<T, MOD, SMALLK>), dim3(grid), dim3(WG_THREADS), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -976,12 +964,7 @@ static int forward_impl(const cinema_siren_desc *d, const float *params, const v
   f.bias = params + d->off_bf;
   f.out_dim = d->out_dim; f.out = out; f.Npad = (int)Npad;
   const int smem = 16 * ((HP + LP) * (int)sizeof(T) + FinalK<T>::PADB);
-  static bool attr_done = false;
-  if (!attr_done) {
-    CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_final_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024 - 1024));
-    attr_done = true;
-  }
+  CINEMA_SMEM_ATTR(k_final_fwd<T>, 160 * 1024 - 1024);
   CINEMA_REQUIRE(smem <= 159 * 1024, "final_linear too wide for LDS staging: hidden %d + lat %d", H, d->lat);
   const int fgrid = (int)std::min<int64_t>(Npad / 64, 1024);
   hipLaunchKernelGGL((k_final_fwd<T>), dim3(fgrid), dim3(WG_THREADS), smem, s, f);
@@ -1010,11 +993,7 @@ extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *par
 template <typename T, bool MOD, bool SMALLK, bool FIRST>
 static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
   constexpr int smem = Engine<T>::NT_SMEM;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (int rc = set_smem_attr<T>((const void *)k_layer_bwd<T, MOD, SMALLK, FIRST>, smem)) return rc;
-    attr_done = true;
-  }
+  CINEMA_SMEM_ATTR((k_layer_bwd<T, MOD, SMALLK, FIRST>), smem);
   hipLaunchKernelGGL((k_layer_bwd<T, MOD, SMALLK, FIRST>), dim3(grid), dim3(WG_THREADS), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1115,11 +1094,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
       if (LP >= 192 && Npad >= 4096 && ns > 0 && HP % DL256_BK == 0) {
         wide = true;
         a.tiles_f = (LP + 255) / 256;
-        static bool attr256 = false;
-        if (!attr256) {
-          CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_dlat256, hipFuncAttributeMaxDynamicSharedMemorySize, DL256_SMEM));
-          attr256 = true;
-        }
+        CINEMA_SMEM_ATTR(k_dlat256, DL256_SMEM);
         hipLaunchKernelGGL(k_dlat256, dim3(a.tiles_f * (int)(Npad / 128)), dim3(DL256_THREADS), DL256_SMEM, s, a);
         CINEMA_CHECK_HIP(hipGetLastError());
       }
@@ -1128,11 +1103,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
       a.tiles_f = (LP + 127) / 128;
       const int g2 = a.tiles_f * (int)(Npad / 128);
       constexpr int smem = Engine<T>::NT_SMEM;
-      static bool attr_done = false;
-      if (!attr_done) {
-        if (int rc = set_smem_attr<T>((const void *)k_dlat<T>, smem)) return rc;
-        attr_done = true;
-      }
+      CINEMA_SMEM_ATTR(k_dlat<T>, smem);
       hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
       CINEMA_CHECK_HIP(hipGetLastError());
     }
@@ -1186,12 +1157,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
         b.g.tile_start[np] = t256;
         b.g.nprob = np;
         b.g.Npad = (int)Npad;
-        static int ncu = 0;
-        if (!ncu) {
-          int dev = 0;
-          CINEMA_CHECK_HIP(hipGetDevice(&dev));
-          CINEMA_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        const int ncu = cinema_cu_count();
         int sk = std::max(1, std::min(DW256_MAX_SPLIT, ncu / std::max(t256, 1)));
         sk = std::min(sk, std::max(1, (int)(Npad / DW256_BN) / 4));
         b.g.splitk = sk;
@@ -1199,11 +1165,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
                        "cinema_siren_backward: gb_extra_bytes of the descriptor is smaller than the plan's");
         const size_t gb_bytes = ((size_t)d->n_gbuf * Npad * HP * sizeof(T) + 255) / 256 * 256;
         b.slab = (float *)((char *)gbuf + gb_bytes);
-        static bool attr256 = false;
-        if (!attr256) {
-          CINEMA_CHECK_HIP(hipFuncSetAttribute((const void *)k_dw256, hipFuncAttributeMaxDynamicSharedMemorySize, DW256_SMEM));
-          attr256 = true;
-        }
+        CINEMA_SMEM_ATTR(k_dw256, DW256_SMEM);
         hipLaunchKernelGGL(k_dw256, dim3(t256 * sk), dim3(DW256_THREADS), DW256_SMEM, s, b);
         CINEMA_CHECK_HIP(hipGetLastError());
         if (pending) {
@@ -1221,11 +1183,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     splitk = std::min(splitk, std::max(1, ntile / 4));
     a.splitk = splitk;
     constexpr int smem = Engine<T>::TN_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (int rc = set_smem_attr<T>((const void *)k_dw_grouped<T>, smem)) return rc;
-      attr_done = true;
-    }
+    CINEMA_SMEM_ATTR(k_dw_grouped<T>, smem);
     hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * splitk), dim3(WG_THREADS), smem, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
   }

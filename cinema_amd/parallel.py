@@ -43,6 +43,8 @@ def agree_steps(local_steps: int, process_group=None, device="cpu") -> int:
     _, world = world_info(process_group)
     if world == 1:
         return local_steps
+    if dist.get_backend(process_group) != "nccl":
+        device = "cpu"                      # gloo: host tensors only (see allreduce_mean_)
     t = torch.tensor([local_steps], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
     return int(t.item())
@@ -58,16 +60,59 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group=None, async_op: bool 
     backend = dist.get_backend(process_group)
     if backend == "nccl":
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=process_group, async_op=async_op)
-    work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=False)
+    if flat_grad.is_cuda:
+        # gloo is a CPU transport.  Handed a device tensor it stages through its own streams and host callbacks, and two
+        # processes sharing one GPU have been seen to sit in that path for minutes (both ranks inside all_reduce).  Keep
+        # the device out of it: finish this rank's queue, copy to a pinned host buffer, reduce on the host, copy back.
+        torch.cuda.current_stream(flat_grad.device).synchronize()
+        host = _host_stage(flat_grad)
+        host.copy_(flat_grad)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+        host.div_(world)
+        flat_grad.copy_(host)
+        return None
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=False)
     flat_grad.div_(world)
     return None
+
+
+def allreduce_sum(t: torch.Tensor, process_group=None) -> torch.Tensor:
+    """Sum a small tensor over ranks (the partial weighted latent sums of the atlas, 27.6 KB); returns the result on
+    t's device.  gloo sees host tensors only (see allreduce_mean_)."""
+    _, world = world_info(process_group)
+    if world == 1:
+        return t
+    if t.is_cuda and dist.get_backend(process_group) != "nccl":
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+        return host.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+    return t
+
+
+_HOST_STAGE: Dict[tuple, torch.Tensor] = {}
+
+
+def _host_stage(t: torch.Tensor) -> torch.Tensor:
+    """Reusable pinned host buffer of t's size and dtype (the gloo rehearsal path on a GPU box only)."""
+    key = (t.numel(), t.dtype)
+    buf = _HOST_STAGE.get(key)
+    if buf is None:
+        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True).view(t.shape)
+        _HOST_STAGE[key] = buf
+    return buf
 
 
 def broadcast_(tensor: torch.Tensor, src: int = 0, process_group=None):
     """Make the replicated parameters identical at start-up (each rank seeds its own latents but must share the MLP)."""
     _, world = world_info(process_group)
     if world > 1:
-        dist.broadcast(tensor, src=src, group=process_group)
+        if tensor.is_cuda and dist.get_backend(process_group) != "nccl":
+            host = tensor.detach().cpu()    # gloo: host tensors only (see allreduce_mean_)
+            dist.broadcast(host, src=src, group=process_group)
+            tensor.copy_(host)
+        else:
+            dist.broadcast(tensor, src=src, group=process_group)
     return tensor
 
 
@@ -77,6 +122,8 @@ def gather_rows(local: torch.Tensor, process_group=None) -> torch.Tensor:
     rank, world = world_info(process_group)
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(process_group) != "nccl":
+        return gather_rows(local.cpu(), process_group).to(local.device)    # gloo: host tensors only
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=process_group)

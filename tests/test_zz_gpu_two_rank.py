@@ -1,7 +1,7 @@
 """Two ranks of the data-parallel trainer on ONE GPU (gloo moves the gradient): replicas stay bit-identical.
-Collected last on purpose (file name): two processes time-slicing one GPU have been seen to stall for seconds per
-collective on the test pool, so the workers run under a deadline and a stall SKIPS the test instead of hanging the
-suite (the driver runs pytest -x without a per-test timeout)."""
+Round 1 saw both ranks sit inside gloo's all_reduce of a DEVICE tensor; since then gloo only ever sees host tensors
+(cinema_amd/parallel.py stages through pinned memory after a stream synchronise).  The workers run under a deadline
+and a stall FAILS the test (the driver runs pytest -x without a per-test timeout, so the deadline is ours)."""
 import os
 import socket
 import time
@@ -72,7 +72,7 @@ def test_two_rank_trainer_step_on_one_gpu(tmp_path):
                 pr.kill()
         for pr in ctx.processes:
             pr.join(10)
-        pytest.skip("two ranks sharing one GPU did not finish one step in 90 s (process time-slicing on this box)")
+        pytest.fail("two ranks sharing one GPU did not finish one trainer step in 90 s")
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
     assert torch.equal(r0["flat0"], r1["flat0"])                   # broadcast at construction
