@@ -15,6 +15,7 @@ BWD_SKIP_WEIGHT_GRADS = 1
 BWD_GRADS_CLEARED, BWD_DCOORDS_CLEARED = 2, 64
 PREPARE_SCRATCH = 260
 PENDING_BYTES = 4096
+NOALLOC_MAX_N, NOALLOC_MAX_S = 65536, 4096
 BWD_PHASE_CHAIN, BWD_PHASE_DLAT, BWD_PHASE_DW, BWD_PHASE_FINAL_DW = 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +66,8 @@ SIGNATURES = {
                          _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
     "cinema_affine_trilerp_bwd": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                   _I32, _I32, _P, _P, _P, _P, _P],
+    "cinema_affine_trilerp_bwd_noalloc": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
+                                          _I32, _I32, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_sorted": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                          _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_sorted_pending": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32,

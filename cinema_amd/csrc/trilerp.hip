@@ -673,3 +673,46 @@ extern "C" int cinema_affine_trilerp_bwd_sorted_pending(const float *coords, con
                           Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream,
                           (const Dw256Args *)pending);
 }
+
+// ----------------------------------------------------------------------------------------
+// cinema_affine_trilerp_bwd for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the grouping scratch (`work` of the call above) is a file-scope device array instead of a caller buffer.
+// Every GPU the library runs on holds its own copy (3.3 MiB) until the process ends; the address is looked up once per
+// device, with that device current, and only that pointer -- never the array's name -- is handed to kernels / memsets.
+// ----------------------------------------------------------------------------------------
+#define NOALLOC_WORDS (2L * CINEMA_NOALLOC_MAX_S + 2 + 13L * CINEMA_NOALLOC_MAX_N)
+static __device__ __align__(256) int32_t scratch[NOALLOC_WORDS];
+
+static int noalloc_scratch(int32_t **out) {
+  static std::atomic<int32_t *> ptr_of[CINEMA_MAX_DEVICES];
+  const int dv = cinema_dev();
+  int32_t *p = ptr_of[dv].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    void *sym = nullptr;
+    CINEMA_CHECK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+    CINEMA_REQUIRE(sym != nullptr, "cinema_affine_trilerp_bwd_noalloc: the scratch symbol has no address on device %d", dv);
+    p = (int32_t *)sym;
+    ptr_of[dv].store(p, std::memory_order_release);
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int cinema_affine_trilerp_bwd_noalloc(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                                 int32_t embed_per_sample, const float *affine, const float *shadow,
+                                                 const float *coords_t, const float *dlat, float *dcoords_t, int64_t N,
+                                                 int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
+                                                 int32_t cond_dims, int32_t LP, float *dlatents, float *dembed, float *dcond,
+                                                 void *stream) {
+  CINEMA_REQUIRE(N >= 1 && N <= CINEMA_NOALLOC_MAX_N && S >= 1 && S <= CINEMA_NOALLOC_MAX_S,
+                 "cinema_affine_trilerp_bwd_noalloc: N = %ld, S = %ld exceed the static scratch (N <= %d, S <= %d); use "
+                 "cinema_affine_trilerp_bwd with a caller-owned work buffer", (long)N, (long)S, CINEMA_NOALLOC_MAX_N,
+                 CINEMA_NOALLOC_MAX_S);
+  int32_t *work = nullptr;
+  if (int rc = noalloc_scratch(&work)) return rc;
+  // nothing in the scratch has to start at zero that the kernels do not write themselves: the one-launch grouping
+  // (k_group_small) fills offsets[0..S] and perm[0..N) completely, the three-launch one clears its counters with a
+  // hipMemsetAsync on `stream` first; the previous call's contents beyond that are never read.
+  return trilerp_bwd_impl(false, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
+                          Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream);
+}

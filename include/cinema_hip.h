@@ -196,6 +196,20 @@ int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32_t *idx, co
                                      int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
                                      float *dlatents, float *dembed, float *dcond, int32_t *work, void *stream);
 
+/* cinema_affine_trilerp_bwd WITHOUT the caller's work buffer.  No counterpart in the reference: it is for callers that
+ * cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The grouping scratch lives in a file-scope device array of the library (2*MAX_S + 2 + 13*MAX_N 4-byte words = 3.3 MiB
+ * per GPU the library runs on, held until the process ends); sizes beyond the maxima are rejected with an error.  The
+ * call allocates and frees nothing.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two
+ * streams, two host threads) race -- serialise them.  Same outputs as cinema_affine_trilerp_bwd. */
+#define CINEMA_NOALLOC_MAX_N 65536
+#define CINEMA_NOALLOC_MAX_S 4096
+int cinema_affine_trilerp_bwd_noalloc(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                      int32_t embed_per_sample, const float *affine, const float *shadow,
+                                      const float *coords_t, const float *dlat, float *dcoords_t, int64_t N, int64_t Npad,
+                                      int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t LP,
+                                      float *dlatents, float *dembed, float *dcond, void *stream);
+
 /* cinema_siren_backward for a training loop that runs the split reduction of the weight-gradient tiles elsewhere: the
  * reduction's arguments are written to `pending` (HOST memory, CINEMA_PENDING_BYTES, opaque) instead of being launched;
  * grad_params holds the bias / first-layer / final-bias gradients only until the pending reduction has run
