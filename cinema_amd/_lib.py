@@ -13,6 +13,8 @@ MAX_LAYERS = 16
 PREC_F32, PREC_BF16 = 0, 1
 BWD_SKIP_WEIGHT_GRADS = 1
 BWD_GRADS_CLEARED, BWD_DCOORDS_CLEARED = 2, 64
+NODES_ROUND_S = 128
+NODE_SLOTS = 32
 PREPARE_SCRATCH = 260
 PENDING_BYTES = 4096
 NOALLOC_MAX_N, NOALLOC_MAX_S = 65536, 4096
@@ -38,6 +40,7 @@ class SirenDesc(C.Structure):
         ("sv_y", _i32L), ("sv_c", _i32L), ("sv_z", _i32L), ("sv_s", _i32L),
         ("gb_z", _i32L), ("gb_s", _i32L), ("gb_t", _i32L),
         ("pk_fs", C.c_int64), ("pk_bs", C.c_int64), ("pk_side", C.c_int64), ("fs_steps", C.c_int32), ("bs_steps", C.c_int32), ("gb_extra_bytes", C.c_int64),
+        ("pk_ns", C.c_int64), ("pk_nb", C.c_int64), ("ns_steps", C.c_int32), ("nb_steps", C.c_int32),
     ]
 
 
@@ -72,6 +75,13 @@ SIGNATURES = {
                                          _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_sorted_pending": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32,
                                                  _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],
+    "cinema_nodes_sizes": [C.POINTER(SirenDesc), _I64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "cinema_node_weights": [_P, _P, _P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
+    "cinema_node_tiles": [_P, _I64, _I64, _I64, _P, _P],
+    "cinema_node_tables": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P],
+    "cinema_siren_forward_nodes": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _P],
+    "cinema_siren_backward_nodes": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _P, _P, _P,
+                                    _I32, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],

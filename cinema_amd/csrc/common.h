@@ -117,6 +117,30 @@ __device__ __forceinline__ int reduce16_index(int i) {
   return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
 }
 
+// The same for 8 per-lane values: every lane of a 16-lane group ends with the group total of value index
+// reduce8_index(lane & 15) (lanes i and i ^ 8 hold the same one).
+__device__ __forceinline__ float reduce8_scatter(float (&v)[8], int lane) {
+  float w4[4], w2[2];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float send = b0 ? v[j] : v[j + 4];
+    const float keep = b0 ? v[j + 4] : v[j];
+    w4[j] = keep + __shfl_xor(send, 1, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float send = b1 ? w4[j] : w4[j + 2];
+    const float keep = b1 ? w4[j + 2] : w4[j];
+    w2[j] = keep + __shfl_xor(send, 2, 64);
+  }
+  const float send = b2 ? w2[0] : w2[1];
+  const float keep = b2 ? w2[1] : w2[0];
+  const float x = keep + __shfl_xor(send, 4, 64);
+  return x + __shfl_xor(x, 8, 64);
+}
+__device__ __forceinline__ int reduce8_index(int i) { return ((i & 1) << 2) | (i & 2) | ((i & 4) >> 2); }
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (bid % 8 equal)
 // get a contiguous range of logical ids, so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

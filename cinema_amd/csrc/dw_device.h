@@ -37,11 +37,11 @@ __device__ __forceinline__ void dw256_reduce_body(const Dw256Args &a, int vbid) 
 
 // dOut [Npad x out_dim] fp32 -> [Npad x 16] T (zero padded) so that the final_linear weight gradient joins the grouped
 // weight-gradient launch as two more problems (P = dOut16, Q = x_L and Q = lat); also reduces the bias gradient.
-// Any workgroup size that is a multiple of 64 up to 512; vbid / vgrid as in step_device.h.
+// Any workgroup size that is a multiple of 64 up to 1024; vbid / vgrid as in step_device.h.
 struct FinalBwdArgs { const float *dout; int out_dim; float *dbf; int Npad; };
 template <typename T>
 __device__ __forceinline__ void dout_prep_body(const FinalBwdArgs &a, T *dout16, unsigned vbid, unsigned vgrid) {
-  __shared__ float red[8][16];
+  __shared__ float red[16][16];
   const int nthr = blockDim.x;
   float colsum[16];
 #pragma unroll

@@ -21,3 +21,14 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
                          hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr);
+
+// "nodes" path (fused_nodes.hip, node.hip; layout in nodes.h): the same chain kernels with the FiLM modulation read from
+// per-subject node tables.  Its forward stream (pk_ns) holds the main weights only.
+int nodes_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t, const void *wrows,
+                  const void *tiles, const void *U, const void *V, int64_t S, int64_t N, int64_t Npad, void *saved, float *out,
+                  int round_s, hipStream_t s);
+int nodes_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *wrows,
+                         const void *tiles, const void *U, int64_t S, const void *saved, const float *dout, int64_t N,
+                         int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads, int round_s, hipStream_t s,
+                         void *dout16 = nullptr, float *dbf = nullptr);
+int fused_pack_nodes(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s);

@@ -34,12 +34,12 @@ void plan_add(StreamPlan &p, long src, int ld, int rows, int cols, int tr, int n
   p.steps += nsteps;
 }
 
-// forward: per layer [s = Wl_scale lat] [z = W x (i > 0)] [t = Wl_shift lat]
-void plan_fwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
+// forward: per layer [s = Wl_scale lat] [z = W x (i > 0)] [t = Wl_shift lat]; nodes path: [z = W x] only
+void plan_fwd_stream(const cinema_siren_desc *d, StreamPlan &p, bool nodes = false) {
   const int H = d->hidden, L = d->lat;
   p.nseg = 0; p.steps = 0;
   for (int i = 0; i < d->n_layers; ++i) {
-    const bool mod = (d->modulated_mask >> i) & 1u;
+    const bool mod = !nodes && ((d->modulated_mask >> i) & 1u);
     if (mod) plan_add(p, d->off_wl[i], L, H, L, 0, ksteps(d->LP));
     if (i > 0) plan_add(p, d->off_w[i], H, H, H, 0, ksteps(d->HP));
     if (mod) plan_add(p, d->off_wl[i] + (long)H * L, L, H, L, 0, ksteps(d->LP));
@@ -54,7 +54,8 @@ void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
 }
 
 // two streams (forward, backward chain) packed by one launch: segments [0, nseg0) belong to stream 0
-struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1; };
+struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1;
+                        int pairmap; };  // 1: fused_nodes.hip's feature map (a lane's fragments 2p, 2p+1 hold 8 consecutive features)
 
 // (vbid, vgrid): the workgroup's index and count among the workgroups doing this job -- the kernels below run either
 // as launches of their own or as block ranges of k_step_head
@@ -72,7 +73,8 @@ __device__ __forceinline__ void pack_stream_body(const PackStreamArgs &a, unsign
     while (si + 1 < send && step >= a.seg[si + 1].step0) ++si;
     const Seg sg = a.seg[si];
     const int kk = step - sg.step0, i = lane & 15, gk = lane >> 4;
-    const int feat = slab * 64 + 16 * (i >> 2) + 4 * ft + (i & 3);
+    const int feat = a.pairmap ? slab * 64 + 32 * (ft >> 1) + 8 * (i >> 2) + 4 * (ft & 1) + (i & 3)
+                               : slab * 64 + 16 * (i >> 2) + 4 * ft + (i & 3);
     const int k0 = 32 * kk + 8 * gk;
     const float *src = a.params + sg.src;
     bf16x8 v;
@@ -160,70 +162,7 @@ __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
 }
 
-// ----------------------------------------------------------------------------------------
-// device: weight ring + segment runner
-// ----------------------------------------------------------------------------------------
-// Addresses are kept as wave-uniform 64-bit bases (SGPRs) + 32-bit per-lane byte offsets so that the only VGPRs
-// alive across the layer loop are the accumulators, the ring and a handful of offsets.
-struct WRing {
-  bf16x8 s[FUSED_RING][4];
-  const char *wp;  // uniform: next step to fetch
-};
-
-__device__ __forceinline__ void ring_fetch(bf16x8 (&slot)[4], const char *p, unsigned lane16) {
-#pragma unroll
-  for (int ft = 0; ft < 4; ++ft) slot[ft] = *reinterpret_cast<const bf16x8 *>(p + ft * 1024 + lane16);
-}
-
-__device__ __forceinline__ void ring_init(WRing &r, const char *stream, unsigned lane16) {
-#pragma unroll
-  for (int k = 0; k < FUSED_RING; ++k) ring_fetch(r.s[k], stream + k * 4096, lane16);
-  r.wp = stream + FUSED_RING * 4096;
-}
-
-// 16-byte chunk c of row `row` of an LDS tile sits at chunk position c ^ (row & 15) (rows are multiples of 256 B):
-// the 16 lanes of every ds_read_b128 lane group then cover all 64 banks exactly once.
-#define FUSED_STEP(SLOT, KSTEP)                                                                              \
-  {                                                                                                          \
-    const int off_ = ((((KSTEP) << 2) + gk) ^ i) << 4;                                                       \
-    bf16x8 b_[NST];                                                                                          \
-    _Pragma("unroll") for (int st = 0; st < NST; ++st)                                                       \
-      b_[st] = *(const LDS_AS bf16x8 *)(tile + rowoff + st * 16 * rowbytes + off_);                          \
-    _Pragma("unroll") for (int ft = 0; ft < 4; ++ft)                                                         \
-      _Pragma("unroll") for (int st = 0; st < NST; ++st)                                                     \
-        acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.s[SLOT][ft], b_[st], acc[ft][st], 0, 0, 0);  \
-    ring_fetch(r.s[SLOT], r.wp, lane16);                                                                     \
-    r.wp += 4096;                                                                                            \
-    __builtin_amdgcn_sched_barrier(0); /* keep the refill here: hipcc otherwise sinks all refills of a group */ \
-  }
-
-// acc[f][n] += sum_k A_stream[f][k] * tile[n][k] over nsteps k32 steps of the wave's weight stream.  Every segment
-// is padded to a multiple of FUSED_RING steps (zero weights against zeroed LDS columns), so the ring phase is always
-// 0 at a segment boundary and the slots are addressed statically (a run-time slot index makes hipcc keep every slot
-// twice and spill; with static slots its own counted vmcnt(15..12) waits come out exact).
-template <int NST>
-__device__ __forceinline__ void run_seg(f32x4 (&acc)[4][NST], WRing &r, const lds_char *tile, int rowbytes, int nsteps,
-                                        int i, int gk, unsigned lane16) {
-  const int rowoff = i * rowbytes;
-  for (int k = 0; k < nsteps; k += 4) {
-    FUSED_STEP(0, k) FUSED_STEP(1, k + 1) FUSED_STEP(2, k + 2) FUSED_STEP(3, k + 3)
-  }
-}
-static_assert(FUSED_RING == 4, "run_seg is written for a 4-step ring");
-
-template <int NST>
-__device__ __forceinline__ void fill_acc(f32x4 (&acc)[4][NST], const f32x4 (&v)[4]) {
-#pragma unroll
-  for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-    for (int st = 0; st < NST; ++st) acc[ft][st] = v[ft];
-}
-
-// v[q] = bias[off + fb + 4q .. +3] from the LDS copy of the biases (each vector zero-padded to HP)
-__device__ __forceinline__ void feature_vec(const lds_char *bias, int off, unsigned fb, f32x4 (&v)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = *(const LDS_AS f32x4 *)(bias + ((off + fb) * 4u + q * 16u));
-}
+#include "fused_dev.h"
 
 // optional phase trace of one wave (tools/trace_fused.py): 100 MHz timestamps
 __device__ long long g_fused_trace[128];
@@ -233,11 +172,6 @@ __device__ long long g_fused_trace[128];
 #else
 #define FUSED_TRACE(ID)
 #endif
-
-__device__ __forceinline__ void pack16(const float (&v)[16], bf16x8 &lo, bf16x8 &hi) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { lo[j] = (bf16_t)v[j]; hi[j] = (bf16_t)v[8 + j]; }
-}
 
 // ----------------------------------------------------------------------------------------
 // fused forward
@@ -703,8 +637,8 @@ bool fused_eligible(const cinema_siren_desc *d) {
 }
 
 void fused_plan(cinema_siren_desc *d, long *pk) {
-  d->pk_fs = d->pk_bs = d->pk_side = -1;
-  d->fs_steps = d->bs_steps = 0;
+  d->pk_fs = d->pk_bs = d->pk_side = d->pk_ns = d->pk_nb = -1;
+  d->fs_steps = d->bs_steps = d->ns_steps = d->nb_steps = 0;
   if (!fused_eligible(d)) return;
   StreamPlan p;
   const long nslab = d->HP / 64;
@@ -715,21 +649,29 @@ void fused_plan(cinema_siren_desc *d, long *pk) {
   d->pk_bs = *pk; d->bs_steps = p.steps;
   *pk += nslab * p.steps * FUSED_STEP_ELEMS;
   *pk += (long)FUSED_RING * FUSED_STEP_ELEMS;  // zero pad: the rings prefetch past the end of the last slab
+  // nodes path: the same two streams without the linear_lats segments
+  plan_fwd_stream(d, p, true);
+  d->pk_ns = *pk; d->ns_steps = p.steps;
+  *pk += nslab * p.steps * FUSED_STEP_ELEMS;
+  plan_bwd_stream(d, p);
+  d->pk_nb = *pk; d->nb_steps = p.steps;
+  *pk += nslab * p.steps * FUSED_STEP_ELEMS;
+  *pk += (long)FUSED_RING * FUSED_STEP_ELEMS;
   d->pk_side = *pk;                            // fp32 side block (biases, first-layer weights) in a T-typed buffer
   *pk += 2L * (fused_bias_floats(d) + 4 * d->HP + 16 * d->HP);
 }
 
 static int fused_pack_args(const cinema_siren_desc *d, const float *params, void *packed, PackStreamArgs &a, PackSideArgs &b,
-                           int &g_ps, int &g_sd) {
+                           int &g_ps, int &g_sd, bool nodes = false) {
   StreamPlan p0, p1;
-  plan_fwd_stream(d, p0);
+  plan_fwd_stream(d, p0, nodes);
   plan_bwd_stream(d, p1);
   CINEMA_REQUIRE(p0.nseg + p1.nseg <= FUSED_MAX_SEGS, "fused_pack: %d segments exceed the table", p0.nseg + p1.nseg);
   for (int k = 0; k < p0.nseg; ++k) a.seg[k] = p0.seg[k];
   for (int k = 0; k < p1.nseg; ++k) a.seg[p0.nseg + k] = p1.seg[k];
   a.nseg0 = p0.nseg; a.nseg1 = p1.nseg; a.steps0 = p0.steps; a.steps1 = p1.steps; a.nslab = d->HP / 64;
-  a.params = params;
-  a.dst0 = (bf16_t *)packed + d->pk_fs; a.dst1 = (bf16_t *)packed + d->pk_bs;
+  a.params = params; a.pairmap = nodes ? 1 : 0;
+  a.dst0 = (bf16_t *)packed + (nodes ? d->pk_ns : d->pk_fs); a.dst1 = (bf16_t *)packed + (nodes ? d->pk_nb : d->pk_bs);
   const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
   CINEMA_REQUIRE(nchunk < (1L << 31), "fused_pack: weight streams too large for 32-bit chunk indices");
   g_ps = (int)std::min<long>((nchunk + 255) / 256, 4096);
@@ -749,12 +691,16 @@ static int fused_pack_args(const cinema_siren_desc *d, const float *params, void
   return 0;
 }
 
-int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) {
+static int fused_pack_impl(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s, bool nodes);
+int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) { return fused_pack_impl(d, params, packed, s, false); }
+int fused_pack_nodes(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s) { return fused_pack_impl(d, params, packed, s, true); }
+
+static int fused_pack_impl(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s, bool nodes) {
   if (d->pk_fs < 0) return 0;
   PackStreamArgs a;
   PackSideArgs b;
   int g_ps = 0, g_sd = 0;
-  if (int rc = fused_pack_args(d, params, packed, a, b, g_ps, g_sd)) return rc;
+  if (int rc = fused_pack_args(d, params, packed, a, b, g_ps, g_sd, nodes)) return rc;
   if (g_ps > 0) {
     hipLaunchKernelGGL(k_pack_stream, dim3(g_ps), dim3(256), 0, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());

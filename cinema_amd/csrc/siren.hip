@@ -865,9 +865,13 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
   };
   // W, W^T and the row-major linear_lats copies are only read by the layer-by-layer kernels
   const bool fwd_layered = fused_mode(d) == 0;
+  const bool nodes = (part & 4) != 0;       // nodes path: forward stream without the linear_lats segments + row-major linear_lats
+  if (nodes && fwd_layered) { cinema_set_error("cinema_siren_pack_part: part 4 needs the activation-stationary bf16 path"); return -1; }
   if (!fwd_layered && (part & 1))
     if (int rc = fused_pack(d, params, packed, s)) return rc;     // weight streams, side block, padded final_linear
-  if (!fwd_layered && !(part & 2)) return 0;
+  if (nodes)
+    if (int rc = fused_pack_nodes(d, params, packed, s)) return rc;
+  if (!fwd_layered && !(part & 2) && !nodes) return 0;
   if (fwd_layered && !(part & 1)) return 0;
   for (int i = 0; i < d->n_layers; ++i) {
     if (i > 0) {
@@ -878,12 +882,14 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
     }
     if ((d->modulated_mask >> i) & 1u) {
       const float *wl = params + d->off_wl[i];
-      if (fwd_layered) {
+      if (fwd_layered || nodes) {
         if (int rc = add(wl, d->pk_wls[i], H, L, L, HP, LP, 0)) return rc;
         if (int rc = add(wl + (size_t)H * L, d->pk_wlt[i], H, L, L, HP, LP, 0)) return rc;
       }
-      if (int rc = add(wl, d->pk_wlsT[i], H, L, L, LP, HP, 1)) return rc;
-      if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
+      if (fwd_layered || (part & 2)) {
+        if (int rc = add(wl, d->pk_wlsT[i], H, L, L, LP, HP, 1)) return rc;
+        if (int rc = add(wl + (size_t)H * L, d->pk_wltT[i], H, L, L, LP, HP, 1)) return rc;
+      }
     }
   }
   // final linear: one job per (output row, x | lat part), padded to 16 rows (fused mode: k_pack_side writes it)
@@ -899,7 +905,7 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
 extern "C" int cinema_siren_pack_part(const cinema_siren_desc *d, const float *params, void *packed, int32_t part,
                                       void *stream) {
   CINEMA_REQUIRE(d && params && packed, "cinema_siren_pack: null argument");
-  CINEMA_REQUIRE(part >= 1 && part <= 3, "cinema_siren_pack_part: part must be 1 (forward), 2 (backward-only) or 3 (both)");
+  CINEMA_REQUIRE(part >= 1 && part <= 7, "cinema_siren_pack_part: part is a mask of 1 (forward), 2 (backward-only), 4 (nodes path)");
   hipStream_t s = (hipStream_t)stream;
   return d->precision == CINEMA_PREC_BF16 ? pack_impl<bf16_t>(d, params, packed, part, s)
                                           : pack_impl<float>(d, params, packed, part, s);
@@ -999,10 +1005,13 @@ static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
   return 0;
 }
 
+struct NodesCtx { const void *wrows; const void *tiles; const void *U; int64_t S; int round_s; };
+
 template <typename T>
 static int backward_impl(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                          const void *lat, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
-                         float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s, Dw256Args *pending = nullptr) {
+                         float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s, Dw256Args *pending = nullptr,
+                         const NodesCtx *nodes = nullptr) {
   // pending != NULL: the split reduction of the 256 x 256 weight-gradient tiles is NOT launched; its arguments go to
   // *pending for the caller to run (cinema_affine_trilerp_bwd_sorted_pending: beside the K1 coordinate gradient)
   if (pending) { pending->g.nprob = 0; pending->slab = nullptr; }
@@ -1028,9 +1037,13 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   {
     // with weight gradients the dOut preparation rides as tail workgroups of the chain launch (it only reads dOut)
     const bool prep_rides = wgrads && all_phases;
-    if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s,
-                                      prep_rides ? (void *)(gb + slot * (d->n_gbuf - 1)) : nullptr,
-                                      prep_rides ? gp + d->off_bf : nullptr))
+    void *d16 = prep_rides ? (void *)(gb + slot * (d->n_gbuf - 1)) : nullptr;
+    float *dbf = prep_rides ? gp + d->off_bf : nullptr;
+    if (nodes != nullptr) {
+      if (int rc = nodes_backward_chain(d, packed, coords_t, nodes->wrows, nodes->tiles, nodes->U, nodes->S, saved, dout, N, Npad,
+                                        gbuf, gp, dcoords, wgrads, nodes->round_s, s, d16, dbf))
+        return rc;
+    } else if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, d16, dbf))
       return rc;
     dout_prep_done = prep_rides;
   }
@@ -1222,4 +1235,34 @@ extern "C" int cinema_siren_backward_deferred(const cinema_siren_desc *d, const 
                                      dcoords, flags, s, (Dw256Args *)pending)
              : backward_impl<float>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
                                     dcoords, flags, s, (Dw256Args *)pending);
+}
+
+// ----------------------------------------------------------------------------------------
+// "nodes" path entry points (nodes.h): the chain kernels read the FiLM modulation from per-subject node tables.
+// ----------------------------------------------------------------------------------------
+extern "C" int cinema_siren_forward_nodes(const cinema_siren_desc *d, const float *params, const void *packed,
+                                          const float *coords_t, const void *wrows, const void *tiles, const void *U,
+                                          const void *V, int64_t S, int64_t N, int64_t Npad, void *saved, float *out,
+                                          int32_t flags, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && wrows && tiles && U && V && out, "cinema_siren_forward_nodes: null argument");
+  CINEMA_REQUIRE(fused_mode(d) == 64 && d->pk_ns >= 0, "cinema_siren_forward_nodes: needs a bf16 stack on the activation-stationary path "
+                 "(hidden <= 512)");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0 && S >= 1, "cinema_siren_forward_nodes: need 1 <= N <= Npad, Npad %% 128 == 0, S >= 1");
+  return nodes_forward(d, params, packed, coords_t, wrows, tiles, U, V, S, N, Npad, saved, out, (flags & CINEMA_NODES_ROUND_S) ? 1 : 0,
+                       (hipStream_t)stream);
+}
+
+extern "C" int cinema_siren_backward_nodes(const cinema_siren_desc *d, const float *params, const void *packed,
+                                           const float *coords_t, const void *lat, const void *wrows, const void *tiles,
+                                           const void *U, int64_t S, const void *saved, const float *dout, int64_t N,
+                                           int64_t Npad, void *gbuf, float *grad_params, float *dlat, float *dcoords,
+                                           int32_t flags, void *pending, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && wrows && tiles && U && saved && dout && gbuf && dlat && dcoords,
+                 "cinema_siren_backward_nodes: null argument");
+  CINEMA_REQUIRE(fused_mode(d) == 64 && d->pk_ns >= 0, "cinema_siren_backward_nodes: needs a bf16 stack on the activation-stationary path");
+  CINEMA_REQUIRE((flags & CINEMA_BWD_SKIP_WEIGHT_GRADS) || grad_params, "cinema_siren_backward_nodes: grad_params is null");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0 && S >= 1, "cinema_siren_backward_nodes: need 1 <= N <= Npad, Npad %% 128 == 0, S >= 1");
+  const NodesCtx nc = {wrows, tiles, U, S, (flags & CINEMA_NODES_ROUND_S) ? 1 : 0};
+  return backward_impl<bf16_t>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat, dcoords,
+                               flags & ~CINEMA_NODES_ROUND_S, (hipStream_t)stream, (Dw256Args *)pending, &nc);
 }

@@ -159,8 +159,20 @@ class SirenEngine:
               "cinema_siren_forward")
         return ws.out
 
+    def forward_nodes(self, n: int, nt: "NodeTables", idx: torch.Tensor, keep: bool = True, round_s: bool = False) -> torch.Tensor:
+        """forward() on the nodes path: ws.coords_t / nt.wrows filled by node_weights, nt.U / nt.V by node_tables."""
+        ws = self.ws
+        npad = round_up(n, ROW_ALIGN)
+        self.version += 1
+        check(self.lib.cinema_siren_forward_nodes(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
+                                                  ptr(nt.wrows), ptr(nt.tiles), ptr(nt.U), ptr(nt.V), nt.S, n, npad,
+                                                  ptr(ws.saved) if keep else None, ptr(ws.out),
+                                                  _lib.NODES_ROUND_S if round_s else 0, self.stream()),
+              "cinema_siren_forward_nodes")
+        return ws.out
+
     def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0,
-                 dcoords_cleared: bool = False, pending=None):
+                 dcoords_cleared: bool = False, pending=None, nodes=None, round_s: bool = False):
         """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords.
         dcoords_cleared: ws.dcoords already holds zeros (step_prepare); flat_grad is not cleared again when a
         clearing optimiser step left it zeroed (grads_clean)."""
@@ -174,6 +186,15 @@ class SirenEngine:
             if self.grads_clean and phases == 0:
                 flags |= _lib.BWD_GRADS_CLEARED
             self.grads_clean = False
+        if nodes is not None:
+            nt, idx = nodes
+            check(self.lib.cinema_siren_backward_nodes(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
+                                                       ptr(ws.lat), ptr(nt.wrows), ptr(nt.tiles), ptr(nt.U), nt.S, ptr(ws.saved),
+                                                       ptr(dout_padded), n, npad, ptr(ws.gbuf), ptr(self.flat_grad), ptr(ws.dlat),
+                                                       ptr(ws.dcoords), flags | (_lib.NODES_ROUND_S if round_s else 0),
+                                                       C.byref(pending) if pending is not None else None, self.stream()),
+                  "cinema_siren_backward_nodes")
+            return
         if pending is not None:
             # the split reduction of the weight-gradient tiles is left to the caller (k1_backward(pending=...) runs it
             # beside the K1 coordinate gradient): flat_grad is complete only after that call
@@ -187,6 +208,56 @@ class SirenEngine:
                                              ptr(ws.lat), ptr(ws.saved), ptr(dout_padded), n, npad, ptr(ws.gbuf),
                                              ptr(self.flat_grad), ptr(ws.dlat), ptr(ws.dcoords), flags, self.stream()),
               "cinema_siren_backward")
+
+
+class NodeTables:
+    """Buffers of the nodes path for one latent table (include/cinema_hip.h, "Nodes" section): node rows T, their
+    projections U / V, and the per-sample weight rows of the current batch."""
+
+    def __init__(self):
+        self.T = self.U = self.V = self.wrows = self.tiles = None
+        self.S = 0
+
+    def ensure(self, eng: "SirenEngine", S: int, rows: int):
+        if self.S != S or self.T is None:
+            t, u, v = C.c_int64(), C.c_int64(), C.c_int64()
+            check(eng.lib.cinema_nodes_sizes(C.byref(eng.desc), S, C.byref(t), C.byref(u), C.byref(v)), "cinema_nodes_sizes")
+            self.T = torch.empty(t.value, device=eng.device, dtype=torch.bfloat16)
+            self.U = torch.zeros(u.value, device=eng.device, dtype=torch.uint8)
+            self.V = torch.zeros(v.value, device=eng.device, dtype=torch.uint8)
+            self.S = S
+        if self.wrows is None or self.wrows.shape[0] < rows:
+            self.wrows = torch.empty(rows, _lib.NODE_SLOTS, device=eng.device, dtype=torch.float16)
+        need = 4 * (rows // 16 + S + 2)
+        if self.tiles is None or self.tiles.numel() < need:
+            self.tiles = torch.zeros(need, device=eng.device, dtype=torch.int32)
+
+
+def nodes_eligible(eng: "SirenEngine", latents_shape) -> bool:
+    """Shapes the nodes path takes: bf16 activation-stationary stack, at most 30 grid nodes."""
+    _, _, lx, ly, lz = latents_shape
+    return eng.can_skip_saved() and eng.desc.pk_ns >= 0 and lx * ly * lz <= 30 and os.environ.get("CINEMA_NODES", "1") != "0"
+
+
+def node_weights(eng: "SirenEngine", nt: NodeTables, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
+                 tfs: Optional[torch.Tensor], n: int):
+    """transform + interpolation weights into eng.ws.coords_t / nt.wrows (rows up to Npad)."""
+    S, _, lx, ly, lz = latents_shape
+    npad = round_up(n, ROW_ALIGN)
+    nt.ensure(eng, S, eng.ws.npad_cap)
+    check(eng.lib.cinema_node_weights(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1], n, npad, S, lx, ly, lz,
+                                      ptr(eng.ws.coords_t), ptr(nt.wrows), eng.stream()), "cinema_node_weights")
+    check(eng.lib.cinema_node_tiles(ptr(idx), n, npad, S, ptr(nt.tiles), eng.stream()), "cinema_node_tiles")
+
+
+def node_tables(eng: "SirenEngine", nt: NodeTables, latents: torch.Tensor, cond_subject: Optional[torch.Tensor]):
+    """Node rows + projections of the current parameters (after eng.pack(4))."""
+    S, Cc, lx, ly, lz = latents.shape
+    cond_dims = 0 if cond_subject is None else cond_subject.shape[1]
+    nt.ensure(eng, S, eng.ws.npad_cap if eng.ws is not None else ROW_ALIGN)
+    check(eng.lib.cinema_node_tables(C.byref(eng.desc), ptr(eng.flat), ptr(eng.packed), ptr(latents),
+                                     ptr(cond_subject) if cond_dims else None, S, Cc, lx, ly, lz, cond_dims, ptr(nt.T), ptr(nt.U),
+                                     ptr(nt.V), eng.stream()), "cinema_node_tables")
 
 
 class TrilerpState:

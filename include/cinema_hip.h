@@ -47,6 +47,8 @@ extern "C" {
  * the call then skips its own hipMemsetAsync of that buffer. */
 #define CINEMA_BWD_GRADS_CLEARED 2
 #define CINEMA_BWD_DCOORDS_CLEARED 64
+/* nodes path: the scale s is rounded to bf16 and saved as on the per-sample path (development / A-B switch) */
+#define CINEMA_NODES_ROUND_S 128
 
 int cinema_version(void);
 const char *cinema_last_error(void);
@@ -92,6 +94,11 @@ typedef struct cinema_siren_desc {
   /* bytes of scratch the caller appends behind the n_gbuf tensors of `gbuf` (fp32 partial tiles of the split
    * weight-gradient reductions; 0 when that path does not apply) */
   int64_t gb_extra_bytes;
+  /* "nodes" path (cinema_node_tables / cinema_siren_forward_nodes): forward weight stream without the linear_lats
+   * segments (their work moves to per-subject node tables) and the backward stream, both per 32-feature slab (16 waves
+   * per workgroup); -1 / 0 when the activation-stationary path does not apply */
+  int64_t pk_ns, pk_nb;
+  int32_t ns_steps, nb_steps;
 } cinema_siren_desc;
 
 int cinema_siren_plan(cinema_siren_desc *d /* host */);
@@ -101,8 +108,9 @@ int cinema_siren_plan(cinema_siren_desc *d /* host */);
  * launch.  Replaces nothing in the reference: it is the layout change that lets
  * siren.py:30-35 run as MFMA GEMMs. */
 int cinema_siren_pack(const cinema_siren_desc *d /* host */, const float *params, void *packed, void *stream);
-/* The same in two parts for a training loop that packs beside other work: part 1 = the copies the forward reads,
- * part 2 = the copies only the backward reads (the forward can start after part 1), 3 = both. */
+/* The same in parts (a mask) for a training loop that packs beside other work: 1 = the copies the forward reads,
+ * 2 = the copies only the backward reads (the forward can start after part 1), 4 = the copies of the nodes path
+ * (forward stream without linear_lats segments, row-major linear_lats for cinema_node_tables). */
 int cinema_siren_pack_part(const cinema_siren_desc *d /* host */, const float *params, void *packed, int32_t part,
                            void *stream);
 
@@ -226,6 +234,52 @@ int cinema_affine_trilerp_bwd_sorted_pending(const float *coords, const int32_t 
                                              int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
                                              int32_t cond_dims, int32_t LP, float *dlatents, float *dembed, float *dcond,
                                              int32_t *work, const void *pending /* host */, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * "Nodes" path of the bf16 chain kernels (hidden <= 512): the FiLM modulation and the latent part of final_linear are
+ * evaluated in NODE space.  linear_lats (models/siren.py:32) and the lat columns of final_linear (siren.py:61) are
+ * linear, and a sample's interpolated latent (models/inr_decoder.py:73-85) is a convex combination of its subject's
+ * grid nodes, so  linear_lats(lat[n]) = sum_k w[n][k] * (Wl * table[s][k]) + bl:  the projections are computed once per
+ * call for the S * G node vectors (cinema_node_tables) instead of N samples, the chain kernels interpolate them with one
+ * fp16 MFMA step per modulated layer and half, and per-sample latent rows never exist.  Same function, different
+ * rounding (fp16 node projections and weights instead of a bf16 GEMM on bf16 latent rows).
+ * Needs lx*ly*lz <= 30 grid nodes; condition values are per SUBJECT (cond_subject [S x cond_dims]; the training loop's
+ * and the atlas evaluation's case).  Per-sample conditions / explicit latent rows use the per-sample entry points.
+ * ------------------------------------------------------------------------------------- */
+/* buffer sizes of the node tables for S subjects: T [t_elems] bf16, U [u_bytes], V [v_bytes] */
+int cinema_nodes_sizes(const cinema_siren_desc *d /* host */, int64_t S, int64_t *t_elems, int64_t *u_bytes, int64_t *v_bytes);
+
+/* INR_Decoder.transform (models/inr_decoder.py:64-71) + the interpolation WEIGHTS of spatial_interpolation (:73-85):
+ *   coords [N x 3], idx [N], embed [S x tf_dim] or NULL -> coords_t [rows x 3] fp32, wrows [rows x 32] fp16
+ *   (8 corner weights of the sample's cell at their nodes' fragment positions, 1.0 in the bias slot; rows >= N zero).
+ * Same registered coordinates, bit for bit, as cinema_affine_trilerp_fwd. */
+int cinema_node_weights(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim, int64_t N, int64_t rows,
+                        int64_t S, int32_t lx, int32_t ly, int32_t lz, float *coords_t, void *wrows, void *stream);
+
+/* Sample tiles of a batch grouped by subject (idx non-decreasing -- the caller's precondition, not checked): every
+ * subject's rows are cut into tiles of at most 16 rows so that each MFMA sample tile of the chain kernels belongs to ONE
+ * subject.  tiles: int32 [4 * (rows / 16 + S + 2)]: word 0 = number of tiles, then {subject, first row, rows, 0} per
+ * tile.  Rows [N, rows) (rows = Npad: the padding of the row buffers) are appended to the last subject. */
+int cinema_node_tiles(const int32_t *idx, int64_t N, int64_t rows, int64_t S, void *tiles, void *stream);
+
+/* Node rows T [S x 32 x LP] bf16 from the latent table (S, C, lx, ly, lz) (+ cond_subject), then their projections
+ * U (linear_lats of every modulated layer, as fp16 MFMA fragments) and V (lat columns of final_linear).
+ * Needs cinema_siren_pack_part(.., 4, ..) of the current parameters. */
+int cinema_node_tables(const cinema_siren_desc *d /* host */, const float *params, const void *packed, const float *latents,
+                       const float *cond_subject, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
+                       void *T, void *U, void *V, void *stream);
+
+/* cinema_siren_forward / cinema_siren_backward on the nodes path: `lat` is replaced by (wrows, tiles, U, V, S); the
+ * batch must be grouped by subject (cinema_node_tiles).
+ * The backward still takes `lat` [Npad x LP] T for the per-sample d-latent / linear_lats weight-gradient GEMMs. */
+int cinema_siren_forward_nodes(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                               const float *coords_t, const void *wrows, const void *tiles, const void *U, const void *V,
+                               int64_t S, int64_t N, int64_t Npad, void *saved, float *out, int32_t flags, void *stream);
+int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                                const float *coords_t, const void *lat, const void *wrows, const void *tiles, const void *U,
+                                int64_t S, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
+                                float *grad_params, float *dlat, float *dcoords, int32_t flags, void *pending /* host, may be NULL */,
+                                void *stream);
 
 /* -------------------------------------------------------------------------------------
  * K3: ground-truth sampling + loss + dLoss/dOutput (Criterion.forward, utils.py:88-104,
