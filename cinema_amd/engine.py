@@ -234,9 +234,10 @@ class NodeTables:
 
 
 def nodes_eligible(eng: "SirenEngine", latents_shape) -> bool:
-    """Shapes the nodes path takes: bf16 activation-stationary stack, at most 30 grid nodes."""
+    """Shapes the nodes path takes: bf16 activation-stationary stack, at most 30 grid nodes.  Opt-in (CINEMA_NODES=1): its
+    chain kernels are not yet faster than the per-sample ones end to end (nodes path)."""
     _, _, lx, ly, lz = latents_shape
-    return eng.can_skip_saved() and eng.desc.pk_ns >= 0 and lx * ly * lz <= 30 and os.environ.get("CINEMA_NODES", "1") != "0"
+    return eng.can_skip_saved() and eng.desc.pk_ns >= 0 and lx * ly * lz <= 30 and os.environ.get("CINEMA_NODES", "0") == "1"
 
 
 def node_weights(eng: "SirenEngine", nt: NodeTables, coords: torch.Tensor, idx: torch.Tensor, latents_shape,

@@ -150,6 +150,7 @@ class HotPathTrainer:
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_prep = torch.cuda.Event()
         self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
+        self.nodes = E.NodeTables()                                    # node-space tables of the nodes path
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -174,6 +175,10 @@ class HotPathTrainer:
         fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
 
         one_head = fast_k1 and eng.can_skip_saved()      # grouped batch on the activation-stationary bf16 path
+        # nodes path: FiLM modulation from per-subject node tables (conditions are per subject here)
+        use_nodes = grouped and E.nodes_eligible(eng, tuple(self.latents.shape))
+        if use_nodes:
+            return self._step_nodes(lo, hi)
 
         def k1_fwd():
             if fast_k1:
@@ -241,6 +246,59 @@ class HotPathTrainer:
             self.opt_mlp.step()
         if self.train_mlp and not self.keep_grads:
             eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
+        self.n_last = n
+
+    def _step_nodes(self, lo: int, hi: int):
+        """step() on the nodes path (grouped batch, bf16 chain kernels)."""
+        st, eng = self.store, self.eng
+        coords, voxel, subj = st.coords[lo:hi], st.voxel[lo:hi], st.subj[lo:hi]
+        n = coords.shape[0]
+        ws = eng.workspace(n)
+        ws.ensure_backward()
+        cond_tab = None
+        cond = None
+        if self.cond_dims:
+            cond_tab = (self.cond_param.data if self.cond_param is not None else st.conditions).contiguous()
+            cond = cond_tab[subj.long()].contiguous()
+        tfs = self.tfs.data
+        use_cw = self.class_w is not None and self.seg_weight > 0
+        nt = self.nodes
+        eng.pack(4 | 2)
+        E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)     # lat rows: the per-sample d-latent / dW GEMMs
+        E.node_weights(eng, nt, coords, subj, tuple(self.latents.shape), tfs, n)
+        E.node_tables(eng, nt, self.latents.data, cond_tab)
+        E.k1_shadow(eng, self.k1, self.latents.data)
+        E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
+                       self.prep_scratch)
+        eng.forward_nodes(n, nt, subj)
+        E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
+                      float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
+                      labels=st.labels, voxels_per_subject=st.V, prepared=True)
+        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, nodes=(nt, subj))
+        work = None
+        if self.train_mlp and self.world > 1:
+            work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+        want_tf = self.tfs.requires_grad
+        _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
+                                    tfs if want_tf else None, False, n, want_latents=True,
+                                    want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
+                                    dlat_out=self.lat_grad, grouped=True)
+        if want_tf and self.tf_weight != 0.0:
+            self._add_tf_regulariser_grad(subj, n)
+        self.latents.grad = self.lat_grad
+        if want_tf:
+            self.tfs.grad = self.tf_grad
+        if self.cond_param is not None:
+            g = torch.zeros_like(self.cond_param)
+            g.index_add_(0, subj.long(), dcond)
+            self.cond_param.grad = g
+        self.opt_local.step()
+        if work is not None:
+            work.wait()
+        if self.opt_mlp is not None:
+            self.opt_mlp.step()
+        if self.train_mlp and not self.keep_grads:
+            eng.grads_clean = True
         self.n_last = n
 
     def _add_tf_regulariser_grad(self, subj, n):

@@ -103,7 +103,18 @@ def test_trainer_step_matches_oracle_full_bench_shape():
     _trainer_step_vs_oracle("bf16", True, S=64, side=28, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], n=25000)
 
 
-def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, layers, mod, n):
+@pytest.mark.parametrize("shape", ["small", "bench"])
+def test_trainer_step_nodes_path_matches_oracle(shape, monkeypatch):
+    """The opt-in nodes path of the bf16 chain kernels (CINEMA_NODES=1: FiLM modulation interpolated from per-subject
+    node projections instead of the per-sample linear_lats GEMM) against the same CPU oracle, same tolerance."""
+    monkeypatch.setenv("CINEMA_NODES", "1")
+    if shape == "small":
+        _trainer_step_vs_oracle("bf16", True, S=5, side=24, latent_dim=[48, 3, 3, 3], hidden=128, layers=3, mod=[1, 3], n=700, nodes=True)
+    else:
+        _trainer_step_vs_oracle("bf16", True, S=64, side=28, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], n=25000, nodes=True)
+
+
+def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, layers, mod, n, nodes=False):
     from oracle import cinema_oracle as O
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
     tol = 1e-4 if precision == "fp32" else 2e-2
@@ -128,8 +139,9 @@ def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, lay
     loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, None, cfg)
     # K3 sampled exactly these targets (bit-exact labels and intensities)
     tgt_dev = torch.empty(n, 3, device=DEV)
-    tr.step(0, n)
     from cinema_amd import engine as E
+    assert E.nodes_eligible(tr.eng, tuple(tr.latents.shape)) == nodes
+    tr.step(0, n)
     sums = torch.zeros(4, device=DEV)
     dout = torch.empty(E.round_up(n, 128), 12, device=DEV)
     E.sample_loss(None, tr.eng.ws.out, n, 2, 10, "mse", tr.class_w, 1.0, 1.0, dout, sums, voxel=store.voxel[:n],

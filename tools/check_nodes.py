@@ -111,3 +111,5 @@ timeit("nodes: tables (rows + projection)", lambda: E.node_tables(eng, nt, laten
 timeit("nodes: forward", lambda: eng.forward_nodes(N, nt, idx))
 timeit("nodes: forward, nothing kept", lambda: eng.forward_nodes(N, nt, idx, keep=False))
 timeit("nodes: backward chain", lambda: eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN, nodes=(nt, idx)))
+timeit("per-sample: backward chain, frozen weights", lambda: eng.backward(N, ws.dout, weight_grads=False, phases=_lib.BWD_PHASE_CHAIN))
+timeit("nodes: backward chain, frozen weights", lambda: eng.backward(N, ws.dout, weight_grads=False, phases=_lib.BWD_PHASE_CHAIN, nodes=(nt, idx)))
