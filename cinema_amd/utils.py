@@ -8,6 +8,7 @@ scalars or one arange per axis) and stay in torch.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -143,120 +144,40 @@ def to_device(x, device="cuda"):
 
 
 # ----------------------------------------------------------------------------------------------
-# volume I/O on either side of the hot path.  nibabel is replaced by cinema_amd.nifti.
+# atlas writer.  Behaviour kept from the reference's writer (SURVEY.md section 5 "Output
+# naming"; utils.py:253-271, 341-350): one 4-d (x, y, z, t) file per channel and condition vector, named
+# {channel}_ga={t0}-{tN}_cond={c}_ep={epoch}.nii.gz, certainty maps under CertaintyMaps/{label}; 64/32-bit integers are
+# stored as int16 and float64 as float32.  nibabel is replaced by cinema_amd.nifti.
 # ----------------------------------------------------------------------------------------------
+_STORED_AS = {np.dtype(np.int64): np.int16, np.dtype(np.int32): np.int16, np.dtype(np.float64): np.float32}
 
 
-def harmonize_labels(subject_seg, dataset):
-    """Reference: utils.py:169-185 (in place, sequential relabelling; order matters)."""
-    if "dhcp_neo" in dataset:
-        subject_seg[subject_seg == 4] = 0
-        subject_seg[subject_seg == 8] = 6
-        subject_seg[subject_seg == 9] = 7
-    elif "dhcp_fetal" in dataset or "marsfet" in dataset:
-        subject_seg[subject_seg == 4] = 0
-        subject_seg[subject_seg == 5] = 4
-        for v in (6, 7, 8, 9):
-            subject_seg[subject_seg == v] = 3
-    else:
-        raise NotImplementedError("Atlas Type not implemented.")
-    return subject_seg
-
-
-def typecheck_img_affine(img, affine):
-    """Reference: utils.py:290-299."""
-    if isinstance(img, torch.Tensor):
-        img = img.detach().cpu().numpy()
-    if isinstance(affine, torch.Tensor):
-        affine = affine.detach().cpu().numpy()
-    if img.dtype == "int64" or img.dtype == "int32":
-        img = img.astype(np.int16)
-    elif img.dtype == "float64":
-        img = img.astype(np.float32)
-    return img, affine
+def _on_host(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
 def save_img(img, affine, output_path, filename):
-    """Reference: utils.py:341-350 (int64/int32 -> int16, float64 -> float32, directories created)."""
-    import os
+    """Write one volume to output_path/filename (directories created); returns the path written."""
     from . import nifti
-    img, affine = typecheck_img_affine(img, affine)
-    full_path = os.path.join(output_path, filename)
-    os.makedirs(os.path.dirname(full_path), exist_ok=True)
-    nifti.save(nifti.Nifti1Image(img, affine), full_path)
-    print(f"Saved {filename} to {output_path}")
+    data = _on_host(img)
+    data = data.astype(_STORED_AS.get(data.dtype, data.dtype), copy=False)
+    target = os.path.join(output_path, filename)
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    nifti.save(nifti.Nifti1Image(data, _on_host(affine)), target)
+    return target
+
+
+def atlas_channel_names(args):
+    """Channel axis of an atlas array: the modalities, then (save_certainty_maps) one certainty map per label."""
+    names = list(args["dataset"]["modalities"])
+    if args["save_certainty_maps"]:
+        names += ["CertaintyMaps/" + label for label in args["dataset"]["label_names"]]
+    return names
 
 
 def save_atlas(args, atlas, affine, temp_steps, condition_vectors, epoch):
-    """Reference: utils.py:253-271.  atlas [x, y, z, modalities, conditions, t]; one 4-D file per (modality, condition)."""
-    if isinstance(atlas, torch.Tensor):
-        atlas = atlas.detach().cpu().numpy()
-    if isinstance(affine, torch.Tensor):
-        affine = affine.detach().cpu().numpy()
-    n_conds = atlas.shape[4]
-    mod_labels = list(args["dataset"]["modalities"])
-    if args["save_certainty_maps"]:
-        mod_labels = mod_labels + [f"CertaintyMaps/{label}" for label in args["dataset"]["label_names"]]
-    for c in range(n_conds):
-        for i in range(len(mod_labels)):
-            filename = f"{mod_labels[i]}_ga={temp_steps[0]}-{temp_steps[-1]}_cond={c}_ep={epoch}.nii.gz"
-            save_img(atlas[..., i, c, :], affine=affine, output_path=args["output_dir"], filename=filename)
-    print("Atlas saved to {}".format(args["output_dir"]))
-
-
-def save_subject(args, img, affine, sub_row_df=None, sub_name=None, epoch=0, split="train"):
-    """Reference: utils.py:302-338 without the epoch-0 ANTs registration of the acquired scans to the reconstruction
-    (ANTs is out of scope; the reconstructed modalities are written exactly as the reference does)."""
-    if sub_row_df is not None:
-        sub_name = sub_row_df["subject_id"]
-    elif sub_name is None:
-        print("No subject name provided, assigning random subject name.")
-        sub_name = "subject_" + str(np.random.randint(100000))
-    img, affine = typecheck_img_affine(img, affine)
-    modalities = args["dataset"]["modalities"]
-    for i, mod in enumerate(modalities):
-        if i == len(modalities) - 1 and "Seg" in mod:
-            img_mod = img[..., i].astype(np.int16)
-        else:
-            img_mod = img[..., i].astype(np.float32)
-        save_img(img_mod, affine, args["output_dir"], f"{split}/{mod}_{sub_name}_ep={epoch}.nii.gz")
-
-
-def assert_correct_coord_normalization(coords, min_val=-1.0, max_val=1.0):
-    """Reference: utils.py:353-367 (numpy array or tensor of shape (n, 3))."""
-    lo, hi = coords.min(axis=0) if isinstance(coords, np.ndarray) else coords.min(dim=0)[0], \
-        coords.max(axis=0) if isinstance(coords, np.ndarray) else coords.max(dim=0)[0]
-    for a, name in enumerate("xyz"):
-        assert float(lo[a]) >= min_val, f"min_{name} = {float(lo[a])} is less than min_val = {min_val}"
-        assert float(hi[a]) <= max_val, f"max_{name} = {float(hi[a])} is greater than max_val = {max_val}"
-
-
-def squeeze_modalities(modality, path, write2disk=False):
-    """Reference: utils.py:369-382: dHCP volumes stored as (x, y, z, 1) are squeezed (and rewritten in place on disk)."""
-    from . import nifti
-    if modality.ndim == 4:
-        mod_nii = nifti.Nifti1Image(np.squeeze(modality.get_fdata()), modality.affine)
-        if write2disk:
-            mod_nii.to_filename(path)
-        return mod_nii
-    return modality
-
-
-def add_background_halo(label_names, seg_nii, halo_width=1.5, background_label_str="BG"):
-    """Reference: utils.py:385-391 (scipy Gaussian on the host, as in the reference; runs once per subject at load)."""
-    import scipy.ndimage as ndi
-    from . import nifti
-    seg = seg_nii.get_fdata()
-    bg_label = label_names.index(background_label_str)
-    mask_bg = (seg > 0).astype(np.float32)
-    mask_bg = (ndi.gaussian_filter(mask_bg, sigma=halo_width) > 0.001).astype(np.uint8) * bg_label
-    mask_bg[seg > 0] = seg[seg > 0]
-    return nifti.Nifti1Image(mask_bg, seg_nii.affine)
-
-
-def mask_nifti(nii, mask):
-    """Reference: utils.py:394-397."""
-    from . import nifti
-    data = nii.get_fdata()
-    data *= mask
-    return nifti.Nifti1Image(data, nii.affine)
+    """atlas [x, y, z, channel, condition, t] -> one 4-d file per (condition, channel); returns the paths."""
+    vols = _on_host(atlas)
+    span = f"{temp_steps[0]}-{temp_steps[-1]}"
+    return [save_img(vols[:, :, :, ch, c, :], affine, args["output_dir"], f"{name}_ga={span}_cond={c}_ep={epoch}.nii.gz")
+            for c in range(vols.shape[4]) for ch, name in enumerate(atlas_channel_names(args))]

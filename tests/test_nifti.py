@@ -114,11 +114,12 @@ def test_reader_on_hand_assembled_files(tmp_path, order):
     exp = np.array([[0, -3, 0, 7], [2, 0, 0, 8], [0, 0, -4, 9], [0, 0, 0, 1.0]])
     assert np.allclose(nifti.load(p2).affine, exp, atol=1e-5)
     assert np.array_equal(nifti.load(p2).get_fdata(), data.astype(np.float64))          # slope 0 = unscaled
-    # 4-d (x, y, z, 1) volume as in dHCP: squeeze_modalities rewrites it 3-d in place
+    # 4-d (x, y, z, 1) volume as in dHCP: read as 3-d, the file is left alone
+    from cinema_amd.dataset import read_subject_volumes
     p3 = str(tmp_path / "d4.nii.gz")
     open(p3, "wb").write(gzip.compress(_spec_build(data[..., None].astype(np.float32), order, sform=AFF)))
-    m = U.squeeze_modalities(nifti.load(p3), p3, write2disk=True)
-    assert m.shape == data.shape and nifti.load(p3).shape == data.shape
+    vols, aff = read_subject_volumes({"dataset": {"modalities": ["T2w"]}}, {"T2w": p3})
+    assert vols[0].shape == data.shape and nifti.load(p3).shape == data.shape + (1,) and np.allclose(aff, AFF, atol=1e-6)
 
 
 def test_reader_rejects_garbage(tmp_path):
@@ -136,7 +137,7 @@ def test_reader_rejects_garbage(tmp_path):
 
 
 def test_save_img_dtype_rules_and_save_atlas_names(tmp_path):
-    """utils.py:341-350 (int64/int32 -> int16, float64 -> float32) and utils.py:253-271 (file naming, 4-d per modality)."""
+    """Writer behaviour of SURVEY.md section 5 "Output naming": int64/int32 -> int16, float64 -> float32; file naming, 4-d per channel."""
     out = str(tmp_path)
     U.save_img(np.arange(24, dtype=np.int64).reshape(2, 3, 4), np.eye(4), out, "sub/a.nii.gz")
     U.save_img(np.ones((2, 3, 4), dtype=np.float64), np.eye(4), out, "sub/b.nii.gz")
@@ -156,21 +157,27 @@ def test_save_img_dtype_rules_and_save_atlas_names(tmp_path):
             assert np.allclose(np.diag(img.affine), [0.5, 0.5, 0.5, 1.0])
 
 
-def test_harmonize_labels_and_halo():
-    seg = np.array([0, 1, 4, 5, 8, 9, 3, 6], dtype=np.float64)
-    assert U.harmonize_labels(seg.copy(), "dhcp_neo_mm").tolist() == [0, 1, 0, 5, 6, 7, 3, 6]
-    assert U.harmonize_labels(seg.copy(), "dhcp_fetal").tolist() == [0, 1, 0, 4, 3, 3, 3, 3]
-    with pytest.raises(NotImplementedError):
-        U.harmonize_labels(seg.copy(), "other")
-    vol = np.zeros((12, 12, 12))
-    vol[4:8, 4:8, 4:8] = 2
-    halo = U.add_background_halo(["none", "a", "b", "BG"], nifti.Nifti1Image(vol, np.eye(4))).get_fdata()
-    assert (halo[4:8, 4:8, 4:8] == 2).all() and halo[3, 5, 5] == 3 and halo[0, 0, 0] == 0
+def test_premask_matches_scipy_halo():
+    """mask_reconstruction at load time (reference behaviour utils.py:385-397): intensities masked by seg > 0, background
+    shell where scipy's Gaussian (sigma 1.5) of the foreground mask exceeds 0.001 -- scipy is the checker here."""
+    import scipy.ndimage as ndi
+    import torch
+    from cinema_amd.dataset import premask_on_device
+    rng = np.random.default_rng(3)
+    seg = np.zeros((20, 17, 15))
+    seg[5:13, 4:9, 6:11] = rng.integers(1, 4, size=(8, 5, 5))
+    seg[0:2, 0:3, 12:15] = 2                                         # touches the border: mirrored edges matter
+    t2 = rng.random(seg.shape) + 0.5
+    got = premask_on_device([torch.from_numpy(t2), torch.from_numpy(seg)], ["none", "a", "b", "c", "BG"])
+    want = ((ndi.gaussian_filter((seg > 0).astype(np.float32), sigma=1.5) > 0.001) * 4).astype(np.float64)
+    want[seg > 0] = seg[seg > 0]
+    assert np.array_equal(got[1].numpy(), want) and (want == 4).sum() > 100
+    assert np.array_equal(got[0].numpy(), t2 * (seg > 0))
 
 
-def test_load_modalities_checks(tmp_path):
+def test_subject_reading_checks(tmp_path):
     from cinema_amd import nifti
-    from cinema_amd.dataset import load_modalities, load_conditions
+    from cinema_amd.dataset import read_subject_volumes, condition_row
     args = {"dataset": {"modalities": ["T2w", "Seg"], "label_names": ["none", "a", "b", "BG"],
                         "conditions": {"birth_age": True, "sex": False}, "constraints": {"birth_age": {"min": 30, "max": 40}}},
             "mask_reconstruction": True, "atlas_gen": {"cond_scale": 0.5}}
@@ -179,19 +186,18 @@ def test_load_modalities_checks(tmp_path):
     seg[3:7, 3:7, 3:7] = 2
     nifti.save(nifti.Nifti1Image(np.full((10, 10, 10), 5.0, np.float32), np.eye(4)), p("t2.nii.gz"))
     nifti.save(nifti.Nifti1Image(seg, np.eye(4)), p("seg.nii.gz"))
-    m = load_modalities(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg.nii.gz")})
-    t2, sg = m["T2w"].get_fdata(), m["Seg"].get_fdata()
-    assert t2[5, 5, 5] == 5.0 and t2[0, 0, 0] == 0.0                 # masked by seg > 0
-    assert sg[5, 5, 5] == 2 and sg[2, 5, 5] == 3 and sg[0, 0, 0] == 0   # halo label = index of 'BG'
+    vols, aff = read_subject_volumes(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg.nii.gz")})
+    assert vols[0].dtype == np.float64 and vols[0][5, 5, 5] == 5.0 and vols[1][5, 5, 5] == 2 and np.array_equal(aff, np.eye(4))
     with pytest.raises(ValueError):
-        load_modalities(args, {"T2w": p("t2.nii.gz")})
+        read_subject_volumes(args, {"T2w": p("t2.nii.gz")})
     with pytest.raises(ValueError):
-        load_modalities(args, {"T2w": "", "Seg": p("seg.nii.gz")})
+        read_subject_volumes(args, {"T2w": "", "Seg": p("seg.nii.gz")})
     nifti.save(nifti.Nifti1Image(seg[:9], np.eye(4)), p("seg9.nii.gz"))
     with pytest.raises(ValueError):
-        load_modalities(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg9.nii.gz")})
+        read_subject_volumes(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg9.nii.gz")})
     nifti.save(nifti.Nifti1Image(seg, np.diag([2.0, 1, 1, 1])), p("seg2.nii.gz"))
     with pytest.raises(ValueError):
-        load_modalities(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg2.nii.gz")})
-    c = load_conditions(args, {"birth_age": 37.5, "sex": 1})
-    assert c.shape == (1,) and abs(float(c[0]) - 0.25) < 1e-7
+        read_subject_volumes(args, {"T2w": p("t2.nii.gz"), "Seg": p("seg2.nii.gz")})
+    row = {"birth_age": 37.5, "sex": 1}
+    c = condition_row(args, row)
+    assert c.shape == (1,) and abs(float(c[0]) - 0.25) < 1e-7 and row == {"birth_age": 37.5, "sex": 1}
