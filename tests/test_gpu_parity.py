@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import L2_TOL, both_errs, failing, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -116,17 +116,19 @@ def test_g5_decoder_golden(name, precision):
     out = dec(coords, lat, cond, tfs, idcs_df=idx)
     loss = crit(out, target, tfs, seg_weight=1.0)
     loss["total"].backward()
-    errs = {"out": rel_err(out.detach().cpu().numpy(), g["out"])}
+    errs = both_errs("out", out.detach().cpu().numpy(), g["out"])
     for k in ("total", "sr", "seg", "tf"):
         errs["loss_" + k] = abs(float(loss[k]) - float(g["loss_" + k])) / max(abs(float(g["loss_" + k])), 1e-12)
-    errs["glat"] = rel_err(lat.grad.cpu().numpy(), g["glat"])
-    errs["gtft"] = rel_err(tft.grad.cpu().numpy(), g["gtft"])
+    errs.update(both_errs("glat", lat.grad.cpu().numpy(), g["glat"]))
+    errs.update(both_errs("gtft", tft.grad.cpu().numpy(), g["gtft"]))
     if c["cond"] > 0:
-        errs["gcond"] = rel_err(cond.grad.cpu().numpy(), g["gcond"])
+        errs.update(both_errs("gcond", cond.grad.cpu().numpy(), g["gcond"]))
     for n, p in dec.named_parameters():
-        errs["g_" + n] = rel_err(p.grad.cpu().numpy(), g["g_" + n])
-    bad = {k: v for k, v in errs.items() if not (v < tol)}
-    assert not bad, f"{name}/{precision}: rel-err above {tol}: {bad}\nall: {errs}"
+        errs.update(both_errs("g_" + n, p.grad.cpu().numpy(), g["g_" + n]))
+    bad = failing(errs, tol, L2_TOL[precision])
+    print(f"{name}/{precision}: worst max-norm {max(v for k, v in errs.items() if not k.endswith('/l2')):.3g}, "
+          f"worst L2 {max(v for k, v in errs.items() if k.endswith('/l2')):.3g}")
+    assert not bad, f"{name}/{precision}: rel-err above {tol} (max-norm) / {L2_TOL[precision]} (L2): {bad}\nall: {errs}"
 
 
 def test_g6_criterion_golden():
@@ -189,14 +191,16 @@ def _oracle_case(N, S, latent_dim, hidden, layers, mod, out_dim, cond, seed, pre
         out = dec(coords.to(dev()), lat_g, cond_g, tfs_for_loss, idcs_df=idx_g)
     loss = crit(out, target.to(dev()), tfs_for_loss, seg_weight=1.0)
     loss["total"].backward()
-    errs = {"out": rel_err(out.detach().cpu().numpy(), out_o.detach().numpy()),
-            "loss": abs(float(loss["total"]) - float(loss_o["total"])) / abs(float(loss_o["total"])),
-            "glat": rel_err(lat_g.grad.cpu().numpy(), lat_o.grad.numpy()),
-            "gtft": rel_err(tft_g.grad.cpu().numpy(), tft_o.grad.numpy())}
+    errs = both_errs("out", out.detach().cpu().numpy(), out_o.detach().numpy())
+    errs["loss"] = abs(float(loss["total"]) - float(loss_o["total"])) / abs(float(loss_o["total"]))
+    errs.update(both_errs("glat", lat_g.grad.cpu().numpy(), lat_o.grad.numpy()))
+    errs.update(both_errs("gtft", tft_g.grad.cpu().numpy(), tft_o.grad.numpy()))
     if cond:
-        errs["gcond"] = rel_err(cond_g.grad.cpu().numpy(), cond_o.grad.numpy())
+        errs.update(both_errs("gcond", cond_g.grad.cpu().numpy(), cond_o.grad.numpy()))
     for n, p in dec.named_parameters():
-        errs["g_" + n] = rel_err(p.grad.cpu().numpy(), params[n[len("sr_net."):]].grad.numpy())
+        errs.update(both_errs("g_" + n, p.grad.cpu().numpy(), params[n[len("sr_net."):]].grad.numpy()))
+    print("worst max-norm %.3g, worst L2 %.3g" % (max(v for k, v in errs.items() if not k.endswith("/l2")),
+                                                  max(v for k, v in errs.items() if k.endswith("/l2"))))
     return errs
 
 
@@ -205,7 +209,7 @@ def test_oracle_parity_ragged_batch(precision):
     """N not a multiple of the 128-row tile, many subjects some of which get no sample, L1 loss."""
     errs = _oracle_case(N=1000, S=37, latent_dim=[48, 3, 3, 3], hidden=256, layers=4, mod=[1, 3], out_dim=[2, 10], cond=1,
                         seed=11, precision=precision, loss_metric="l1")
-    bad = {k: v for k, v in errs.items() if not (v < TOL[precision])}
+    bad = failing(errs, TOL[precision], L2_TOL[precision])
     assert not bad, f"{bad}\nall: {errs}"
 
 
@@ -214,7 +218,7 @@ def test_oracle_parity_dhcp_shape_tf_table(precision):
     """cfg-D dimensions (latent 256x3^3, hidden 512, out 2+10) at N = 4096, S = 16; tf table mode."""
     errs = _oracle_case(N=4096, S=16, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[2, 10],
                         cond=0, seed=12, precision=precision, tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < TOL[precision])}
+    bad = failing(errs, TOL[precision], L2_TOL[precision])
     assert not bad, f"{bad}\nall: {errs}"
 
 
@@ -224,7 +228,7 @@ def test_oracle_parity_wide_ragged_256_tiles():
     (hidden > 256 and <= 512 also takes the activation-stationary chains)."""
     errs = _oracle_case(N=5000, S=9, latent_dim=[64, 2, 2, 2], hidden=320, layers=3, mod=[1, 2], out_dim=[1, 6], cond=1,
                         seed=23, precision="bf16", tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    bad = failing(errs, TOL["bf16"], L2_TOL["bf16"])
     assert not bad, f"{bad}\nall: {errs}"
 
 
@@ -233,7 +237,7 @@ def test_oracle_parity_wide_latent_257():
     waves idle), hidden 256, N = 4200."""
     errs = _oracle_case(N=4200, S=5, latent_dim=[256, 1, 1, 1], hidden=256, layers=2, mod=[1, 2], out_dim=[1, 6], cond=1,
                         seed=29, precision="bf16", tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    bad = failing(errs, TOL["bf16"], L2_TOL["bf16"])
     assert not bad, f"{bad}\nall: {errs}"
 
 
@@ -244,7 +248,7 @@ def test_oracle_parity_mixed_chain_tiles(n):
     bench's batch size and the smallest batch that takes the plan."""
     errs = _oracle_case(N=n, S=11, latent_dim=[32, 3, 3, 3], hidden=128, layers=3, mod=[1, 3], out_dim=[2, 10], cond=0,
                         seed=31, precision="bf16", tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    bad = failing(errs, TOL["bf16"], L2_TOL["bf16"])
     assert not bad, f"{bad}\nall: {errs}"
 
 
@@ -254,15 +258,56 @@ def test_oracle_parity_full_bench_shape():
     mixed 64 / 48-sample chain tiles, 256 x 256 weight-gradient tiles with 7 sample splits, the wide d-latent GEMM."""
     errs = _oracle_case(N=25000, S=64, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[2, 10],
                         cond=0, seed=41, precision="bf16", tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < TOL["bf16"])}
+    bad = failing(errs, TOL["bf16"], L2_TOL["bf16"])
     assert not bad, f"{bad}\nall: {errs}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_oracle_parity_hidden_1024_reference_default_width(precision):
+    """hidden_size 1024, the reference's default (configs/config_atlas.yaml:78): above FUSED_MAX_HP, so the
+    layer-by-layer kernels (128 x 128 tiles) run.  Parity against the CPU oracle at N = 3000, then one timing line at the
+    bench batch size (N = 25 000) so this width has a measured number (printed; `pytest -s` or the captured log)."""
+    shape = dict(latent_dim=[256, 3, 3, 3], hidden=1024, layers=5, mod=[1, 3, 5], out_dim=[2, 10], cond=0)
+    errs = _oracle_case(N=3000, S=8, seed=43, precision=precision, tf_table=True, **shape)
+    bad = failing(errs, TOL[precision], L2_TOL[precision])
+    assert not bad, f"{bad}\nall: {errs}"
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import Criterion
+    n, S = 25000, 64
+    args = make_args(shape["latent_dim"], 1024, 5, [1, 3, 5], [2, 10], 0, precision, loss_metric="mse",
+                     class_weights=[0.0] + [1.0] * 9, tf_weight=0.0)
+    torch.manual_seed(3)
+    dec, crit = INR_Decoder(args, "cuda:0").to(dev()), Criterion(args)
+    lat = (torch.randn(S, 256, 3, 3, 3, device=dev()) * 0.05).requires_grad_(True)
+    tft = ((torch.rand(S, 6, device=dev()) - 0.5) * 0.1).requires_grad_(True)
+    coords = torch.rand(n, 3, device=dev()) * 1.9 - 0.95
+    idx = torch.randint(0, S, (n,), device=dev(), dtype=torch.int32)
+    target = torch.cat((torch.rand(n, 2, device=dev()), torch.randint(1, 10, (n, 1), device=dev()).float()), 1)
+
+    def step():
+        out = dec(coords, lat, torch.zeros(n, 0, device=dev()), tft, idcs_df=idx, tf_table=True)
+        crit(out, target, tft[idx.long()], seg_weight=1.0)["total"].backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    flops = 2 * 3 * (3 * 1024 + 5 * 1024 * 1024 + 3 * 256 * 2048 + (1024 + 256) * 12) * n
+    print(f"hidden 1024 / {precision}: fwd + loss + bwd through the module API {ms:.3f} ms at N = {n} "
+          f"({n / ms * 1e3 / 1e6:.2f} M samples/s, {flops / ms / 1e9:.0f} TFLOP/s algorithmic)")
+    assert ms < 50.0
 
 
 def test_oracle_parity_large_batch_grouping_path():
     """N above the single-launch grouping limit (65536): the histogram / scan / fill launches and many sample tiles."""
     errs = _oracle_case(N=70001, S=7, latent_dim=[16, 2, 2, 2], hidden=64, layers=2, mod=[1], out_dim=[1, 4], cond=0,
                         seed=19, precision="fp32", tf_table=True)
-    bad = {k: v for k, v in errs.items() if not (v < 2e-4)}     # sums over 10^4 samples per subject in fp32
+    bad = failing(errs, 2e-4, 1e-4)     # sums over 10^4 samples per subject in fp32
     assert not bad, f"{bad}\nall: {errs}"
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import L2_TOL, both_errs, failing, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -149,12 +149,12 @@ def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, lay
     assert torch.equal(tgt_dev.cpu(), target)
     got = tr.loss_dict()
     assert abs(got["total"] - float(loss_o["total"])) < tol * abs(float(loss_o["total"]))
-    errs = {"glat": rel_err(tr.lat_grad.cpu().numpy(), lat_o.grad.numpy()),
-            "gtf": rel_err(tr.tf_grad.cpu().numpy(), tf_o.grad.numpy())}
+    errs = both_errs("glat", tr.lat_grad.cpu().numpy(), lat_o.grad.numpy())
+    errs.update(both_errs("gtf", tr.tf_grad.cpu().numpy(), tf_o.grad.numpy()))
     gviews = tr.eng.param_views(tr.eng.flat_grad.cpu())
     for k, p in params.items():
-        errs["g_" + k] = rel_err(gviews[k].numpy(), p.grad.numpy())
-    bad = {k: v for k, v in errs.items() if not v < tol}
+        errs.update(both_errs("g_" + k, gviews[k].numpy(), p.grad.numpy()))
+    bad = failing(errs, tol, L2_TOL[precision])
     assert not bad, bad
     # one AdamW step from the trainer's own gradients
     ref_p = [torch.nn.Parameter(lat0.clone()), torch.nn.Parameter(tf0.clone()), torch.nn.Parameter(flat0.clone())]
