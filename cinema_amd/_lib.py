@@ -13,6 +13,7 @@ MAX_LAYERS = 16
 PREC_F32, PREC_BF16 = 0, 1
 BWD_SKIP_WEIGHT_GRADS = 1
 BWD_GRADS_CLEARED, BWD_DCOORDS_CLEARED = 2, 64
+BWD_WEIGHTS_FIRST, BWD_DLAT_ONLY = 256, 512
 NODES_ROUND_S = 128
 NODE_SLOTS = 32
 PREPARE_SCRATCH = 260
@@ -84,6 +85,7 @@ SIGNATURES = {
                                     _I32, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
+    "cinema_sample_loss_fwd_bwd_normed": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P, _P],
     "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],
     "cinema_infer_minmax": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_infer_finish": [_P, _I64, _I32, _I32, _P, _P, _P],

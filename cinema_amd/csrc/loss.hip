@@ -27,6 +27,7 @@ struct LossArgs {
   const float *out; const float *target; const int64_t *voxel; const int32_t *subj; const float *intens;
   const uint8_t *labels; long V, N, Npad; int sr_dims, n_cls, metric; const float *class_w;
   float sr_scale, seg_scale; float *sums; float *dout; float *target_out; int wsum_on_device;
+  const float *norm;   // optional fp32[2]: {samples, class-weight sum} that normalise the means (data-parallel ranks), else N / sums[2]
 };
 
 template <int MAXC>
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void k_sample_loss(LossArgs a) {
   const int od = a.sr_dims + a.n_cls;
   const int tcols = a.sr_dims + 1;
   float acc_sr = 0.f, acc_ce = 0.f, acc_w = 0.f;
-  const float wtot = a.wsum_on_device ? a.sums[2] : (float)a.N;
-  const float inv_sr = a.sr_scale / ((float)a.N * (float)a.sr_dims);
+  const float wtot = a.norm ? a.norm[1] : (a.wsum_on_device ? a.sums[2] : (float)a.N);
+  const float inv_sr = a.sr_scale / ((a.norm ? a.norm[0] : (float)a.N) * (float)a.sr_dims);
   const float inv_w = wtot > 0.f ? a.seg_scale / wtot : 0.f;
   for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < a.Npad; n += (long)gridDim.x * blockDim.x) {
     float *drow = a.dout + n * od;
@@ -167,7 +168,7 @@ static int sample_loss_impl(bool prepared, const float *out, const float *target
                             const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
                             int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
                             float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
-                            void *stream) {
+                            void *stream, const float *norm = nullptr) {
   CINEMA_REQUIRE(out && sums && dout, "cinema_sample_loss_fwd_bwd: null argument");
   CINEMA_REQUIRE(target || (voxel && subj && intens && labels), "cinema_sample_loss_fwd_bwd: need a dense target or volumes");
   CINEMA_REQUIRE(N >= 1 && Npad >= N, "cinema_sample_loss_fwd_bwd: bad sizes");
@@ -183,7 +184,7 @@ static int sample_loss_impl(bool prepared, const float *out, const float *target
     CINEMA_CHECK_HIP(hipGetLastError());
   }
   LossArgs a = {out, target, voxel, subj, intens, labels, (long)V, (long)N, (long)Npad, sr_dims, n_cls, loss_metric, class_w,
-                sr_scale, seg_scale, sums, dout, target_out, wdev};
+                sr_scale, seg_scale, sums, dout, target_out, wdev, norm};
   hipLaunchKernelGGL(k_sample_loss<16>, dim3(grid), dim3(256), 0, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -205,6 +206,16 @@ extern "C" int cinema_sample_loss_fwd_bwd_prepared(const float *out, const float
                                                    float *dout, float *target_out, void *stream) {
   return sample_loss_impl(true, out, target, voxel, subj, intens, labels, V, N, Npad, sr_dims, n_cls, loss_metric, class_w,
                           sr_scale, seg_scale, sums, dout, target_out, stream);
+}
+
+extern "C" int cinema_sample_loss_fwd_bwd_normed(const float *out, const float *target, const int64_t *voxel,
+                                                 const int32_t *subj, const float *intens, const uint8_t *labels, int64_t V,
+                                                 int64_t N, int64_t Npad, int32_t sr_dims, int32_t n_cls, int32_t loss_metric,
+                                                 const float *class_w, float sr_scale, float seg_scale, float *sums,
+                                                 float *dout, float *target_out, const float *norm, void *stream) {
+  CINEMA_REQUIRE(norm != nullptr, "cinema_sample_loss_fwd_bwd_normed: norm is NULL");
+  return sample_loss_impl(true, out, target, voxel, subj, intens, labels, V, N, Npad, sr_dims, n_cls, loss_metric, class_w,
+                          sr_scale, seg_scale, sums, dout, target_out, stream, norm);
 }
 
 extern "C" int cinema_step_prepare(float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const int32_t *subj,

@@ -1017,8 +1017,12 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   if (pending) { pending->g.nprob = 0; pending->slab = nullptr; }
   const int H = d->hidden, L = d->lat, HP = d->HP, LP = d->LP, nl = d->n_layers;
   const bool wgrads = !(flags & CINEMA_BWD_SKIP_WEIGHT_GRADS);
-  const int phases = (flags & CINEMA_BWD_PHASE_MASK) ? (flags & CINEMA_BWD_PHASE_MASK) : CINEMA_BWD_PHASE_MASK;
-  const bool all_phases = phases == CINEMA_BWD_PHASE_MASK;
+  const bool weights_first = flags & CINEMA_BWD_WEIGHTS_FIRST, dlat_only = flags & CINEMA_BWD_DLAT_ONLY;
+  CINEMA_REQUIRE(!(weights_first && dlat_only) && !((weights_first || dlat_only) && (flags & CINEMA_BWD_PHASE_MASK)),
+                 "cinema_siren_backward: WEIGHTS_FIRST, DLAT_ONLY and the phase bits exclude each other");
+  const int phases = weights_first ? (CINEMA_BWD_PHASE_MASK & ~CINEMA_BWD_PHASE_DLAT) : dlat_only ? CINEMA_BWD_PHASE_DLAT
+                     : (flags & CINEMA_BWD_PHASE_MASK) ? (flags & CINEMA_BWD_PHASE_MASK) : CINEMA_BWD_PHASE_MASK;
+  const bool all_phases = phases == CINEMA_BWD_PHASE_MASK || weights_first;   // a two-call backward keeps full semantics
   const T *pk = (const T *)packed;
   const T *sv = (const T *)saved;
   T *gb = (T *)gbuf;

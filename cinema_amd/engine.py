@@ -172,17 +172,19 @@ class SirenEngine:
         return ws.out
 
     def backward(self, n: int, dout_padded: torch.Tensor, weight_grads: bool = True, phases: int = 0,
-                 dcoords_cleared: bool = False, pending=None, nodes=None, round_s: bool = False):
+                 dcoords_cleared: bool = False, pending=None, nodes=None, round_s: bool = False, part: int = 0):
         """dout_padded: [>= Npad x out_dim] fp32 with zero rows >= n.  Fills flat_grad, ws.dlat, ws.dcoords.
         dcoords_cleared: ws.dcoords already holds zeros (step_prepare); flat_grad is not cleared again when a
-        clearing optimiser step left it zeroed (grads_clean)."""
+        clearing optimiser step left it zeroed (grads_clean).
+        part: 0 = the whole backward; _lib.BWD_WEIGHTS_FIRST = everything but the d-latent GEMM (flat_grad complete on
+        return: a data-parallel rank starts its all-reduce here); _lib.BWD_DLAT_ONLY = the d-latent GEMM afterwards."""
         ws = self.ws
         ws.ensure_backward()
         npad = round_up(n, ROW_ALIGN)
-        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | phases
+        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | phases | part
         if dcoords_cleared:
             flags |= _lib.BWD_DCOORDS_CLEARED
-        if weight_grads:
+        if weight_grads and part != _lib.BWD_DLAT_ONLY:
             if self.grads_clean and phases == 0:
                 flags |= _lib.BWD_GRADS_CLEARED
             self.grads_clean = False
@@ -402,13 +404,22 @@ def sample_loss(eng_or_device, out: torch.Tensor, n: int, sr_dims: int, n_cls: i
                 sums: torch.Tensor, target: Optional[torch.Tensor] = None, voxel: Optional[torch.Tensor] = None,
                 subj: Optional[torch.Tensor] = None, intens: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, voxels_per_subject: int = 0,
-                target_out: Optional[torch.Tensor] = None, prepared: bool = False):
+                target_out: Optional[torch.Tensor] = None, prepared: bool = False, norm: Optional[torch.Tensor] = None):
     """K3: GT sampling + loss sums + dLoss/dOutput in one launch (see include/cinema_hip.h).
-    prepared: `sums` was set up by step_prepare (no memset, no class-weight pre-pass)."""
+    prepared: `sums` was set up by step_prepare (no memset, no class-weight pre-pass).
+    norm: device fp32[2] {samples, class-weight sum} per rank of the union batch (data-parallel ranks; needs prepared)."""
     lib = _lib.load()
     device = out.device
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     npad = min(round_up(n, ROW_ALIGN), dout.shape[0])
+    if norm is not None:
+        if not prepared or norm.dtype != torch.float32 or norm.numel() != 2 or norm.device != device:
+            raise ValueError("sample_loss: norm is a device fp32[2] tensor and needs prepared sums")
+        check(lib.cinema_sample_loss_fwd_bwd_normed(ptr(out), ptr(target), ptr(voxel), ptr(subj), ptr(intens), ptr(labels),
+                                                    voxels_per_subject, n, npad, sr_dims, n_cls, 0 if loss_metric == "mse" else 1,
+                                                    ptr(class_w), float(sr_scale), float(seg_scale), ptr(sums), ptr(dout),
+                                                    ptr(target_out), ptr(norm), stream), "cinema_sample_loss_fwd_bwd_normed")
+        return
     fn = lib.cinema_sample_loss_fwd_bwd_prepared if prepared else lib.cinema_sample_loss_fwd_bwd
     check(fn(ptr(out), ptr(target), ptr(voxel), ptr(subj), ptr(intens), ptr(labels),
              voxels_per_subject, n, npad, sr_dims, n_cls, 0 if loss_metric == "mse" else 1,

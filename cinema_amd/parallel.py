@@ -51,9 +51,9 @@ def agree_steps(local_steps: int, process_group=None, device="cpu") -> int:
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, process_group=None, async_op: bool = False):
-    """Average the replicated MLP's flat gradient over ranks in place.  With equal per-rank sample counts and a
-    mean-reduced loss this is the gradient of the same loss on the union batch (tests/test_dp_gloo.py).  RCCL has a
-    native AVG; gloo has not, so sum and scale there."""
+    """Average the replicated MLP's flat gradient over ranks in place.  With the per-rank losses normalised by the union
+    batch's counts (share_batch_normaliser_) this is the gradient of the same loss on the union batch
+    (tests/test_dp_gloo.py).  RCCL has a native AVG; gloo has not, so sum and scale there."""
     _, world = world_info(process_group)
     if world == 1:
         return None
@@ -74,6 +74,39 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group=None, async_op: bool 
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=False)
     flat_grad.div_(world)
     return None
+
+
+class _UnionNormaliser:
+    """Handle of share_batch_normaliser_: wait() leaves norm = union-batch sums / world on the current stream."""
+
+    def __init__(self, norm, work, world):
+        self.norm, self.work, self.world = norm, work, world
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.norm.mul_(1.0 / self.world)
+        return self.norm
+
+
+def share_batch_normaliser_(norm: torch.Tensor, process_group=None):
+    """norm = fp32[2] {samples, sum of class weights} of THIS rank's batch; after .wait() it holds the union batch's sums
+    divided by the number of ranks.  A rank that normalises its mean losses by these (instead of its own counts) turns
+    the rank-AVERAGE of the gradients into the union batch's gradient also when class weights make the cross-entropy
+    denominators differ between ranks or when a rank runs a shorter last chunk (utils.py:57-79 on the union batch).
+    RCCL: started asynchronously (8 bytes; it hides under the forward pass); gloo: host tensors only, synchronous."""
+    _, world = world_info(process_group)
+    if world == 1:
+        return _UnionNormaliser(norm, None, 1)
+    if dist.get_backend(process_group) == "nccl":
+        return _UnionNormaliser(norm, dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=process_group, async_op=True), world)
+    if norm.is_cuda:
+        host = norm.detach().cpu()          # synchronises this rank's queue; gloo never sees the device
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+        norm.copy_(host)
+    else:
+        dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=process_group)
+    return _UnionNormaliser(norm, None, world)
 
 
 def allreduce_sum(t: torch.Tensor, process_group=None) -> torch.Tensor:

@@ -142,6 +142,7 @@ class HotPathTrainer:
                 if opt is not None:
                     self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
         self.sums = torch.zeros(4, device=self.device)
+        self.norm = torch.zeros(2, device=self.device)               # union-batch normaliser of a data-parallel rank
         # Grouped batches on the bf16 chain kernels need no second stream: everything in front of the forward is ONE
         # launch (cinema_step_head).  The fallback shapes keep the backward-only preparation (transposed linear_lats copies,
         # node-major shadow, per-step clearing + class-weight normaliser) on a side stream that joins before the loss
@@ -212,19 +213,25 @@ class HotPathTrainer:
             eng.pack(1)
             k1_fwd()
             backward_only_prep()
+        norm = self._union_normaliser(n, use_cw, joined)      # rank of several: started here, hidden under the forward
         eng.forward(n)
         if not joined:
             main.wait_event(self.ev_prep)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
-                      labels=st.labels, voxels_per_subject=st.V, prepared=True)
+                      labels=st.labels, voxels_per_subject=st.V, prepared=True, norm=None if norm is None else norm.wait())
         # one rank: nobody needs the flat gradient before the optimiser, so the split reduction of the weight-gradient
         # tiles rides with the K1 backward's first launch (beside the coordinate gradient) instead of a launch of its own
         pending = self.pending if (grouped and self.train_mlp and self.world == 1) else None
-        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, pending=pending)
         work = None
         if self.train_mlp and self.world > 1:
+            # rank of several: weight gradients first, their all-reduce starts at once and runs beside the d-latent GEMM,
+            # the K1 backward and the table-side AdamW
+            eng.backward(n, ws.dout, weight_grads=True, dcoords_cleared=True, part=_lib.BWD_WEIGHTS_FIRST)
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+            eng.backward(n, ws.dout, weight_grads=True, part=_lib.BWD_DLAT_ONLY)
+        else:
+            eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, pending=pending)
         want_tf = self.tfs.requires_grad
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
@@ -248,6 +255,20 @@ class HotPathTrainer:
             eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
         self.n_last = n
 
+    def _union_normaliser(self, n: int, use_cw: bool, prepared_on_main: bool):
+        """Rank of several: {samples, class-weight sum} of the union batch / world (parallel.share_batch_normaliser_), as
+        the loss kernel's normaliser.  None for one process."""
+        if self.world == 1:
+            return None
+        if not prepared_on_main:
+            torch.cuda.current_stream(self.device).wait_event(self.ev_prep)      # sums[2] comes from the side stream
+        self.norm[0] = float(n)
+        if use_cw:
+            self.norm[1:2].copy_(self.sums[2:3])
+        else:
+            self.norm[1] = float(n)
+        return par.share_batch_normaliser_(self.norm, self.pg)
+
     def _step_nodes(self, lo: int, hi: int):
         """step() on the nodes path (grouped batch, bf16 chain kernels)."""
         st, eng = self.store, self.eng
@@ -270,14 +291,18 @@ class HotPathTrainer:
         E.k1_shadow(eng, self.k1, self.latents.data)
         E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
                        self.prep_scratch)
+        norm = self._union_normaliser(n, use_cw, True)
         eng.forward_nodes(n, nt, subj)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
-                      labels=st.labels, voxels_per_subject=st.V, prepared=True)
-        eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, nodes=(nt, subj))
+                      labels=st.labels, voxels_per_subject=st.V, prepared=True, norm=None if norm is None else norm.wait())
         work = None
         if self.train_mlp and self.world > 1:
+            eng.backward(n, ws.dout, weight_grads=True, dcoords_cleared=True, nodes=(nt, subj), part=_lib.BWD_WEIGHTS_FIRST)
             work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+            eng.backward(n, ws.dout, weight_grads=True, nodes=(nt, subj), part=_lib.BWD_DLAT_ONLY)
+        else:
+            eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, nodes=(nt, subj))
         want_tf = self.tfs.requires_grad
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,

@@ -42,6 +42,10 @@ extern "C" {
 #define CINEMA_BWD_PHASE_DW 16       /* grouped weight-gradient GEMMs (one launch) */
 #define CINEMA_BWD_PHASE_FINAL_DW 32 /* final_linear weight / bias gradients */
 #define CINEMA_BWD_PHASE_MASK 60
+/* Data-parallel order: a first call with WEIGHTS_FIRST runs everything but the d-latent GEMM (the flat gradient is
+ * complete when it returns, so its all-reduce can start), a second call with DLAT_ONLY runs the d-latent GEMM. */
+#define CINEMA_BWD_WEIGHTS_FIRST 256
+#define CINEMA_BWD_DLAT_ONLY 512
 /* The caller already holds zeros in grad_params / in dcoords (a training loop clears them off the critical path:
  * cinema_adamw_step_clear leaves zeroed gradients behind, cinema_step_prepare zeroes dcoords on a side stream):
  * the call then skips its own hipMemsetAsync of that buffer. */
@@ -309,6 +313,17 @@ int cinema_sample_loss_fwd_bwd_prepared(const float *out, const float *target, c
                                         int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
                                         float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
                                         void *stream);
+
+/* The prepared call for one rank of a data-parallel job (reference: utils.py:57-79 evaluated on the union of the ranks'
+ * batches; the reference itself is single-device).  norm = device fp32[2] = {samples, sum of class_w[label]} of the UNION
+ * batch divided by the number of ranks: the means and dOut are normalised by these instead of N and sums[2], so that
+ * the rank-average of the gradients is the union batch's gradient also with non-uniform class weights or ragged N
+ * (without class_w pass norm[1] = norm[0]). */
+int cinema_sample_loss_fwd_bwd_normed(const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
+                                      const float *intens, const uint8_t *labels, int64_t V, int64_t N, int64_t Npad,
+                                      int32_t sr_dims, int32_t n_cls, int32_t loss_metric, const float *class_w,
+                                      float sr_scale, float seg_scale, float *sums, float *dout, float *target_out,
+                                      const float *norm, void *stream);
 
 /* Per-step clearing for a training loop (build_atlas.py:69-88 does optimizer.zero_grad() + a loss per step), ONE launch:
  * zeroes dcoords [n_dcoords] fp32 (may be NULL) and sums[0..3]; with class_w it also sets sums[2] to the sum of

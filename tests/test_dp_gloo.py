@@ -122,6 +122,43 @@ def test_flat_gradient_allreduce_equals_union_batch():
     _run(_grad_worker)
 
 
+def _ragged_weighted_worker(rank):
+    """Non-uniform class weights and ragged n (rank 1 runs a shorter chunk): each rank normalises its means by the union
+    batch's counts / world (par.share_batch_normaliser_), then the rank-average of the gradients is the union batch's."""
+    O, params, latents, tfs, batches, cfg = _problem()
+    names = O.siren_param_names(LAYERS, MOD)
+    cw = torch.tensor([0.0, 1.0, 2.5, 0.5])
+    keep = [N_PER_RANK, N_PER_RANK - 17]
+    batches = [tuple(t[:keep[r]] for t in b) for r, b in enumerate(batches)]
+    for b in batches:                      # class 0 has weight 0, as the background class of the configs
+        b[1][:, 1].clamp_(min=0)
+    own = par.shard_subjects(S_TOTAL, rank, WORLD)
+    p_loc = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lat_loc, tf_loc = latents[own].clone().requires_grad_(True), tfs[own].clone().requires_grad_(True)
+    coords, target, subj = batches[rank]
+    y = target[:, 1].long()
+    norm = par.share_batch_normaliser_(torch.tensor([float(len(y)), float(cw[y].sum())])).wait()
+    n_union, w_union = sum(keep), sum(float(cw[b[1][:, 1].long()].sum()) for b in batches)
+    assert torch.allclose(norm, torch.tensor([n_union / WORLD, w_union / WORLD]))
+    local = subj - own[0]
+    out = O.decoder_forward(p_loc, coords, lat_loc, None, tf_loc[local.long()], local, cfg["num_hidden_layers"], *cfg["omega"])
+    nll = torch.nn.functional.cross_entropy(out[:, 1:], y, reduction="none")
+    loss = ((out[:, :1] - target[:, :1]) ** 2).sum() / (norm[0] * 1) + (cw[y] * nll).sum() / norm[1]
+    loss.backward()
+    flat_grad = _flat(p_loc, names, grad=True).clone()
+    par.allreduce_mean_(flat_grad)
+    p_u = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lat_u, tf_u = latents.clone().requires_grad_(True), tfs.clone().requires_grad_(True)
+    cu = torch.cat([b[0] for b in batches]); tu = torch.cat([b[1] for b in batches]); su = torch.cat([b[2] for b in batches])
+    O.training_step(p_u, lat_u, tf_u, cu, tu, su, None, dict(cfg, class_weights=cw))
+    assert rel_err(flat_grad.numpy(), _flat(p_u, names, grad=True).numpy()) < 1e-5
+    assert rel_err(lat_loc.grad.numpy(), WORLD * lat_u.grad[own].numpy()) < 1e-5
+
+
+def test_ragged_weighted_batches_allreduce_equals_union_batch():
+    _run(_ragged_weighted_worker)
+
+
 # ------------------------------------------------------------------ helpers with ragged shards
 def _helpers_worker(rank):
     assert par.world_info() == (rank, WORLD)

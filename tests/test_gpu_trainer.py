@@ -183,6 +183,7 @@ def test_clearing_step_equals_keeping_step(precision, as_rank_of_two, monkeypatc
         monkeypatch.setattr(par, "world_info", lambda pg=None: (0, 2))
         monkeypatch.setattr(par, "broadcast_", lambda t, src=0, pg=None: t)
         monkeypatch.setattr(par, "allreduce_mean_", lambda g, pg=None, async_op=False: None)
+        monkeypatch.setattr(par, "share_batch_normaliser_", lambda norm, pg=None: par._UnionNormaliser(norm, None, 1))
     args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
     store = SubjectStore.synthetic(5, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
     store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=700)

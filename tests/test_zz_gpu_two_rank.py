@@ -29,7 +29,9 @@ def _trainer_args():
         "optimizer": {"tf_weight": 0.0, "loss_metric": "mse", "seg_weight": 1.0, "lr_inr": 1e-4, "inr_weight_decay": 0.0,
                       "lr_latent": 5e-4, "latent_weight_decay": 0.0, "lr_tf": 7.5e-3, "tf_weight_decay": 0.0,
                       "scheduler": {"type": "cosine", "eta_min": 2.5e-5}},
-        "dataset": {"class_weights": None, "world_bbox": [155, 155, 155], "label_names": []},
+        # non-uniform class weights: the cross-entropy denominators of the two ranks differ
+        "dataset": {"class_weights": [0.0, 1.0, 2.5, 0.5, 1.0, 3.0, 1.0, 0.25, 1.0, 2.0], "world_bbox": [155, 155, 155],
+                    "label_names": []},
         "epochs": {"train": 5, "val": 5}, "mask_reconstruction": False, "device": DEV,
     }
 
@@ -46,19 +48,26 @@ def _dp_worker(rank, port, out_dir):
         store.shuffle(torch.Generator(device=DEV).manual_seed(7 + rank))
         tr = HotPathTrainer(_trainer_args(), store, DEV, keep_grads=True)
         flat0 = tr.eng.flat.detach().cpu().clone()
-        n = 512
+        n = 512 - 130 * rank                                       # ragged: rank 1 runs a shorter chunk
+        base = store.subj[:n].long() * store.V + store.voxel[:n]
+        batch = {"coords": store.coords[:n].cpu(), "subj": store.subj[:n].cpu(), "lat": tr.latents.detach().cpu().clone(),
+                 "tfs": tr.tfs.detach().cpu().clone(),
+                 "target": torch.cat((store.intens[base], store.labels[base].float().unsqueeze(1)), 1).cpu()}
         tr.step(0, n)
         torch.cuda.synchronize()
         out = {"flat0": flat0, "flat1": tr.eng.flat.detach().cpu(), "grad": tr.eng.flat_grad.detach().cpu(),
-               "loss": tr.loss_dict()["total"]}
+               "loss": tr.loss_dict()["total"], "batch": batch,
+               "views0": {k: v.clone() for k, v in tr.eng.param_views(flat0).items()},
+               "gviews": {k: v.clone() for k, v in tr.eng.param_views(tr.eng.flat_grad.detach().cpu()).items()}}
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_rank_trainer_step_on_one_gpu(tmp_path):
-    """Two processes, subjects sharded, MLP replicated: after one step both replicas hold identical weights, started
-    from rank 0's initialisation, and the all-reduced gradient is the mean of the two local gradients."""
+    """Two processes, subjects sharded, MLP replicated, non-uniform class weights, ragged n: after one step (weight
+    gradients first, all-reduce, then the d-latent GEMM) both replicas hold identical weights, started from rank 0's
+    initialisation, and the all-reduced gradient is the union batch's gradient (CPU oracle)."""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.start_processes(_dp_worker, args=(port, str(tmp_path)), nprocs=2, join=False, start_method="spawn")
@@ -80,5 +89,19 @@ def test_two_rank_trainer_step_on_one_gpu(tmp_path):
     assert torch.equal(r0["flat1"], r1["flat1"])                   # replicas stay bit-identical after AdamW
     assert not torch.equal(r0["flat0"], r0["flat1"])
     assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"]) and r0["loss"] != r1["loss"]   # different shards
-    # the numerical identity of the averaged gradient with the union-batch gradient is covered on the CPU by
-    # tests/test_dp_gloo.py (same helper, gloo backend)
+    # the averaged gradient IS the union batch's: the CPU oracle on both ranks' samples at once (class-weighted
+    # cross-entropy over the union, ragged n), rank 0's initial weights
+    from conftest import rel_err
+    from oracle import cinema_oracle as O
+    b0, b1 = r0["batch"], r1["batch"]
+    S0 = b0["lat"].shape[0]
+    params = {k: v.clone().requires_grad_(True) for k, v in r0["views0"].items()}
+    lat = torch.cat((b0["lat"], b1["lat"])).requires_grad_(True)
+    tfs = torch.cat((b0["tfs"], b1["tfs"])).requires_grad_(True)
+    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse", tf_weight=0.0,
+               class_weights=torch.tensor(_trainer_args()["dataset"]["class_weights"]))
+    O.training_step(params, lat, tfs, torch.cat((b0["coords"], b1["coords"])), torch.cat((b0["target"], b1["target"])),
+                    torch.cat((b0["subj"], b1["subj"] + S0)), None, cfg)
+    bad = {k: rel_err(r0["gviews"][k].numpy(), p.grad.numpy()) for k, p in params.items()}
+    bad = {k: v for k, v in bad.items() if not v < 1e-4}
+    assert not bad, bad
