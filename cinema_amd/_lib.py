@@ -25,6 +25,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CINEMA_HIP_LIB") or os.path.join(_HERE, "libcinema_hip.so")   # override: developer builds
 
 
+class SineLayerDesc(C.Structure):
+    """Mirror of `cinema_sine_layer_desc` (include/cinema_hip.h)."""
+    _fields_ = [("in_feat", C.c_int32), ("lat_feat", C.c_int32), ("out_feat", C.c_int32), ("precision", C.c_int32),
+                ("omega", C.c_float)]
+
+
 class SirenDesc(C.Structure):
     """Mirror of `cinema_siren_desc` (include/cinema_hip.h)."""
     _i64L = C.c_int64 * MAX_LAYERS
@@ -87,10 +93,13 @@ SIGNATURES = {
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_normed": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P, _P],
     "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],
+    "cinema_sine_layer_work_bytes": [_P, _I64],
+    "cinema_sine_layer_forward": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "cinema_sine_layer_backward": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cinema_infer_minmax": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_infer_finish": [_P, _I64, _I32, _I32, _P, _P, _P],
 }
-_RESTYPES = {"cinema_last_error": C.c_char_p}
+_RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64}
 
 _lib = None
 

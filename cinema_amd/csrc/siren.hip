@@ -754,6 +754,21 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
   pack_job_body<T>(a.job[blockIdx.y], a.packed, blockIdx.x, gridDim.x);
 }
 
+// stand-alone sine layer helpers: identity operand, padded T / fp32 rows -> dense fp32 rows
+template <typename T>
+__global__ __launch_bounds__(256) void k_eye(T *dst, int n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)n * n; e += (long)gridDim.x * 256)
+    dst[e] = (T)((e / n == e % n) ? 1.f : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpad(const T *src, int ld, float *dst, long rows, int cols) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * cols; e += (long)gridDim.x * 256) {
+    const long r = e / cols;
+    dst[e] = (float)src[r * ld + (e - r * cols)];
+  }
+}
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
@@ -1269,4 +1284,223 @@ extern "C" int cinema_siren_backward_nodes(const cinema_siren_desc *d, const flo
   const NodesCtx nc = {wrows, tiles, U, S, (flags & CINEMA_NODES_ROUND_S) ? 1 : 0};
   return backward_impl<bf16_t>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat, dcoords,
                                flags & ~CINEMA_NODES_ROUND_S, (hipStream_t)stream, (Dw256Args *)pending, &nc);
+}
+
+// ----------------------------------------------------------------------------------------
+// stand-alone SineLayer.forward / backward (models/siren.py:26-36) over the layer-by-layer kernels
+// ----------------------------------------------------------------------------------------
+namespace {
+struct SineLayerPlan {
+  int H, HP, K, KP, L, LP; bool small, mod; long Npad; size_t esz;
+  // element offsets (of T) into the work buffer, then byte offsets of the fp32 regions
+  long W, WT, Wls, Wlt, WlsT, WltT, eye, X, LAT, Y, C, Z, S, G, DZ, DS, DT, t_end;
+  size_t xs, dxp, dlp, bytes;
+};
+
+bool sine_layer_plan(const cinema_sine_layer_desc *d, int64_t N, SineLayerPlan &p) {
+  if (!d || N < 1 || d->in_feat < 1 || d->out_feat < 16 || d->out_feat % 16 || d->lat_feat < 0) return false;
+  if (d->precision != CINEMA_PREC_F32 && d->precision != CINEMA_PREC_BF16) return false;
+  p.H = d->out_feat; p.HP = round_up(p.H, 64);
+  p.K = d->in_feat; p.small = p.K <= 3; p.KP = round_up(p.K, 64);
+  p.L = d->lat_feat; p.mod = p.L > 0; p.LP = p.mod ? round_up(p.L, 64) : 0;
+  p.Npad = (N + 127) / 128 * 128;
+  p.esz = d->precision == CINEMA_PREC_BF16 ? 2 : 4;
+  long o = 0;
+  auto take = [&](long n) { const long at = o; o += (n + 127) / 128 * 128; return at; };
+  const long HP = p.HP, KP = p.KP, LP = p.LP, NP = p.Npad;
+  p.W = take(p.small ? 0 : HP * KP); p.WT = take(p.small ? 0 : KP * HP);
+  p.Wls = take(HP * LP); p.Wlt = take(HP * LP); p.WlsT = take(LP * HP); p.WltT = take(LP * HP);
+  p.eye = take(HP * HP);
+  p.X = take(p.small ? 0 : NP * KP); p.LAT = take(NP * LP);
+  p.Y = take(NP * HP); p.C = take(NP * HP); p.Z = take(p.mod ? NP * HP : 0); p.S = take(p.mod ? NP * HP : 0);
+  p.G = take(NP * HP); p.DZ = take(NP * HP); p.DS = take(p.mod ? NP * HP : 0); p.DT = take(p.mod ? NP * HP : 0);
+  p.t_end = o;
+  size_t b = (size_t)o * p.esz;
+  auto takeb = [&](size_t n) { const size_t at = b; b += (n + 255) / 256 * 256; return at; };
+  p.xs = takeb(p.small ? (size_t)NP * p.K * 4 : 0);
+  p.dxp = takeb((size_t)NP * (p.small ? p.K : KP) * 4);
+  p.dlp = takeb((size_t)NP * LP * 4);
+  p.bytes = b;
+  return true;
+}
+
+template <typename T>
+int sine_layer_forward_impl(const cinema_sine_layer_desc *d, const SineLayerPlan &p, const float *x, const float *latent,
+                            const float *W, const float *b, const float *Wl, const float *bl, int64_t N, void *work,
+                            float *out, hipStream_t s) {
+  T *wk = (T *)work;
+  PackArgs a;
+  a.packed = work;
+  int nj = 0;
+  auto add = [&](const float *src, long dst, long rows, int cols, int ld, long rowsP, int colsP, int tr) {
+    PackJob j = {src, dst, (int)rows, cols, ld, (int)rowsP, colsP, tr};
+    a.job[nj++] = j;
+  };
+  if (!p.small) {
+    add(W, p.W, p.H, p.K, p.K, p.HP, p.KP, 0);          // [HP x KP]: forward operand
+    add(W, p.WT, p.H, p.K, p.K, p.KP, p.HP, 1);         // [KP x HP]: d input = dz W
+    add(x, p.X, N, p.K, p.K, p.Npad, p.KP, 0);
+  }
+  if (p.mod) {
+    add(Wl, p.Wls, p.H, p.L, p.L, p.HP, p.LP, 0);
+    add(Wl + (size_t)p.H * p.L, p.Wlt, p.H, p.L, p.L, p.HP, p.LP, 0);
+    add(Wl, p.WlsT, p.H, p.L, p.L, p.LP, p.HP, 1);
+    add(Wl + (size_t)p.H * p.L, p.WltT, p.H, p.L, p.L, p.LP, p.HP, 1);
+    add(latent, p.LAT, N, p.L, p.L, p.Npad, p.LP, 0);
+  }
+  if (nj) {
+    a.njobs = nj;
+    hipLaunchKernelGGL((k_pack<T>), dim3(64, nj), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  float *xs = (float *)((char *)work + p.xs);
+  if (p.small) {
+    CINEMA_CHECK_HIP(hipMemsetAsync(xs, 0, (size_t)p.Npad * p.K * 4, s));
+    CINEMA_CHECK_HIP(hipMemcpyAsync(xs, x, (size_t)N * p.K * 4, hipMemcpyDeviceToDevice, s));
+  }
+  FwdArgs f = {};
+  f.bias = b; f.H = p.H; f.HP = p.HP; f.ldo = p.HP; f.tiles_f = (p.HP + 127) / 128; f.omega = d->omega;
+  f.Y = wk + p.Y; f.C = wk + p.C; f.rowsW = p.HP;
+  if (p.mod) {
+    f.LAT = wk + p.LAT; f.LP = p.LP; f.Wls = wk + p.Wls; f.Wlt = wk + p.Wlt; f.bias_l = bl;
+    f.Z = wk + p.Z; f.S = wk + p.S;
+  }
+  const int grid = f.tiles_f * (int)(p.Npad / 128);
+  int rc;
+  if (p.small) {
+    f.Xs = xs; f.ldxs = p.K; f.ks = p.K; f.Ws = W; f.ws_sf = p.K; f.ws_sk = 1;
+    rc = p.mod ? launch_fwd<T, true, true>(f, grid, s) : launch_fwd<T, false, true>(f, grid, s);
+  } else {
+    f.X = wk + p.X; f.ldx = p.KP; f.W = wk + p.W; f.K = p.KP;
+    rc = p.mod ? launch_fwd<T, true, false>(f, grid, s) : launch_fwd<T, false, false>(f, grid, s);
+  }
+  if (rc) return rc;
+  const unsigned ug = (unsigned)std::min<long>((N * p.H + 255) / 256, 4096);
+  hipLaunchKernelGGL((k_unpad<T>), dim3(ug), dim3(256), 0, s, (const T *)(wk + p.Y), p.HP, out, (long)N, p.H);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int sine_layer_backward_impl(const cinema_sine_layer_desc *d, const SineLayerPlan &p, const float *W, int64_t N, void *work,
+                             const float *dout, float *dx, float *dlatent, float *dW, float *db, float *dWl, float *dbl,
+                             hipStream_t s) {
+  T *wk = (T *)work;
+  float *xs = (float *)((char *)work + p.xs), *dxp = (float *)((char *)work + p.dxp), *dlp = (float *)((char *)work + p.dlp);
+  CINEMA_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)p.H * p.K * 4, s));
+  CINEMA_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)p.H * 4, s));
+  if (p.mod) {
+    CINEMA_CHECK_HIP(hipMemsetAsync(dWl, 0, (size_t)2 * p.H * p.L * 4, s));
+    CINEMA_CHECK_HIP(hipMemsetAsync(dbl, 0, (size_t)2 * p.H * 4, s));
+  }
+  if (p.small) CINEMA_CHECK_HIP(hipMemsetAsync(dxp, 0, (size_t)p.Npad * p.K * 4, s));
+  {
+    PackArgs a;
+    a.packed = work;
+    PackJob j = {dout, p.G, (int)N, p.H, p.H, (int)p.Npad, p.HP, 0};
+    a.job[0] = j;
+    a.njobs = 1;
+    hipLaunchKernelGGL((k_pack<T>), dim3(64, 1), dim3(256), 0, s, a);
+    CINEMA_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_eye<T>), dim3(256), dim3(256), 0, s, wk + p.eye, p.HP);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  BwdArgs a = {};
+  a.G = wk + p.G; a.ldg = p.HP; a.WT = wk + p.eye; a.Kred = p.HP; a.rowsWT = p.HP;     // dy itself: identity operand
+  a.C = wk + p.C; a.ldo = p.HP; a.HP = p.HP; a.H = p.H; a.omega = d->omega; a.tiles_f = (p.HP + 127) / 128;
+  a.DZ = wk + p.DZ; a.db = db;
+  if (p.mod) { a.Z = wk + p.Z; a.S = wk + p.S; a.DS = wk + p.DS; a.DT = wk + p.DT; a.dbl = dbl; }
+  if (p.small) { a.coords = xs; a.in_dim = p.K; a.W0 = W; a.dW0 = dW; a.dcoords = dxp; }
+  const int grid = a.tiles_f * (int)(p.Npad / 128);
+  int rc;
+  if (p.small) rc = p.mod ? launch_bwd<T, true, false, true>(a, grid, s) : launch_bwd<T, false, false, true>(a, grid, s);
+  else rc = p.mod ? launch_bwd<T, true, false, false>(a, grid, s) : launch_bwd<T, false, false, false>(a, grid, s);
+  if (rc) return rc;
+  auto dlat_gemm = [&](const NtSeg *segs, int ns, int cols, int colsP, float *outp) -> int {
+    DlatArgs g = {};
+    for (int q = 0; q < ns; ++q) g.seg[q] = segs[q];
+    g.nseg = ns; g.ks = 0; g.lat = cols; g.LP = colsP; g.ldg = p.HP; g.out = outp;
+    g.tiles_f = (colsP + 127) / 128;
+    constexpr int smem = Engine<T>::NT_SMEM;
+    CINEMA_SMEM_ATTR(k_dlat<T>, smem);
+    hipLaunchKernelGGL((k_dlat<T>), dim3(g.tiles_f * (int)(p.Npad / 128)), dim3(WG_THREADS), smem, s, g);
+    CINEMA_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+  auto unpad = [&](const float *src, int ld, float *dst, int cols) -> int {
+    const unsigned ug = (unsigned)std::min<long>((N * cols + 255) / 256, 4096);
+    hipLaunchKernelGGL((k_unpad<float>), dim3(ug), dim3(256), 0, s, src, ld, dst, (long)N, cols);
+    CINEMA_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+  if (p.small) {
+    if (int r2 = unpad(dxp, p.K, dx, p.K)) return r2;
+  } else {
+    NtSeg sg = {wk + p.WT, wk + p.DZ, p.HP};
+    if (int r2 = dlat_gemm(&sg, 1, p.K, p.KP, dxp)) return r2;
+    if (int r2 = unpad(dxp, p.KP, dx, p.K)) return r2;
+  }
+  if (p.mod) {
+    NtSeg sg[2] = {{wk + p.WlsT, wk + p.DS, p.HP}, {wk + p.WltT, wk + p.DT, p.HP}};
+    if (int r2 = dlat_gemm(sg, 2, p.L, p.LP, dlp)) return r2;
+    if (int r2 = unpad(dlp, p.LP, dlatent, p.L)) return r2;
+  }
+  DwArgs w = {};
+  int np = 0, tiles = 0;
+  auto add = [&](const void *P, const void *Q, float *o, int ldq, int ldo, int K) {
+    DwProb pr = {P, Q, o, p.HP, ldq, ldo, p.H, K, (K + 127) / 128};
+    w.p[np] = pr;
+    w.tile_start[np] = tiles;
+    tiles += ((p.H + 127) / 128) * pr.tk;
+    ++np;
+  };
+  if (!p.small) add(wk + p.DZ, wk + p.X, dW, p.KP, p.K, p.K);
+  if (p.mod) {
+    add(wk + p.DS, wk + p.LAT, dWl, p.LP, p.L, p.L);
+    add(wk + p.DT, wk + p.LAT, dWl + (size_t)p.H * p.L, p.LP, p.L, p.L);
+  }
+  if (np) {
+    w.tile_start[np] = tiles; w.nprob = np; w.Npad = (int)p.Npad;
+    const int ntile = (int)(p.Npad / Engine<T>::BN);
+    w.splitk = std::min(std::max(1, 512 / std::max(tiles, 1)), std::max(1, ntile / 4));
+    constexpr int smem = Engine<T>::TN_SMEM;
+    CINEMA_SMEM_ATTR(k_dw_grouped<T>, smem);
+    hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * w.splitk), dim3(WG_THREADS), smem, s, w);
+    CINEMA_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t cinema_sine_layer_work_bytes(const cinema_sine_layer_desc *d, int64_t N) {
+  SineLayerPlan p;
+  if (!sine_layer_plan(d, N, p)) {
+    cinema_set_error("cinema_sine_layer_work_bytes: need N >= 1, in_feat >= 1, out_feat a multiple of 16, lat_feat >= 0, a valid precision");
+    return -1;
+  }
+  return (int64_t)p.bytes;
+}
+
+extern "C" int cinema_sine_layer_forward(const cinema_sine_layer_desc *d, const float *x, const float *latent, const float *W,
+                                         const float *b, const float *Wl, const float *bl, int64_t N, void *work, float *out,
+                                         void *stream) {
+  SineLayerPlan p;
+  CINEMA_REQUIRE(sine_layer_plan(d, N, p), "cinema_sine_layer_forward: bad descriptor or N (see cinema_sine_layer_work_bytes)");
+  CINEMA_REQUIRE(x && W && b && work && out, "cinema_sine_layer_forward: null argument");
+  CINEMA_REQUIRE(!p.mod || (latent && Wl && bl), "cinema_sine_layer_forward: a modulated layer needs latent, linear_lats weight and bias");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16 ? sine_layer_forward_impl<bf16_t>(d, p, x, latent, W, b, Wl, bl, N, work, out, s)
+                                          : sine_layer_forward_impl<float>(d, p, x, latent, W, b, Wl, bl, N, work, out, s);
+}
+
+extern "C" int cinema_sine_layer_backward(const cinema_sine_layer_desc *d, const float *W, int64_t N, void *work,
+                                          const float *dout, float *dx, float *dlatent, float *dW, float *db, float *dWl,
+                                          float *dbl, void *stream) {
+  SineLayerPlan p;
+  CINEMA_REQUIRE(sine_layer_plan(d, N, p), "cinema_sine_layer_backward: bad descriptor or N (see cinema_sine_layer_work_bytes)");
+  CINEMA_REQUIRE(W && work && dout && dx && dW && db, "cinema_sine_layer_backward: null argument");
+  CINEMA_REQUIRE(!p.mod || (dlatent && dWl && dbl), "cinema_sine_layer_backward: a modulated layer needs dlatent, dWl and dbl");
+  hipStream_t s = (hipStream_t)stream;
+  return d->precision == CINEMA_PREC_BF16 ? sine_layer_backward_impl<bf16_t>(d, p, W, N, work, dout, dx, dlatent, dW, db, dWl, dbl, s)
+                                          : sine_layer_backward_impl<float>(d, p, W, N, work, dout, dx, dlatent, dW, db, dWl, dbl, s);
 }

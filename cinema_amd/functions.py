@@ -3,8 +3,11 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes as C
+
 import torch
 
+from . import _lib
 from . import engine as E
 
 
@@ -173,3 +176,44 @@ class LossFunction(torch.autograd.Function):
     def backward(ctx, g_total, g_sr, g_ce):
         (dout,) = ctx.saved_tensors
         return dout[:ctx.n] * g_total, None, None, None, None, None, None
+
+
+class SineLayerFunction(torch.autograd.Function):
+    """SineLayer.forward of the reference (models/siren.py:26-36) as one C-ABI call each way
+    (cinema_sine_layer_forward / _backward, include/cinema_hip.h).  latent / wl / bl are None for an unmodulated layer."""
+
+    @staticmethod
+    def forward(ctx, desc, x, latent, w, b, wl, bl):
+        lib = _lib.load()
+        n = x.shape[0]
+        mod = desc.lat_feat > 0
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        x32, lat32, w32, b32, wl32, bl32 = f32(x), f32(latent) if mod else None, f32(w), f32(b), f32(wl) if mod else None, \
+            f32(bl) if mod else None
+        nbytes = lib.cinema_sine_layer_work_bytes(C.byref(desc), n)
+        if nbytes < 0:
+            _lib.check(-1, "cinema_sine_layer_work_bytes")
+        work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty(n, desc.out_feat, dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.cinema_sine_layer_forward(C.byref(desc), _lib.ptr(x32), _lib.ptr(lat32), _lib.ptr(w32), _lib.ptr(b32),
+                                                 _lib.ptr(wl32), _lib.ptr(bl32), n, _lib.ptr(work), _lib.ptr(out), stream),
+                   "cinema_sine_layer_forward")
+        ctx.desc, ctx.n, ctx.work, ctx.w32, ctx.mod = desc, n, work, w32, mod
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        d, n, dev = ctx.desc, ctx.n, gout.device
+        z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        dx, dw, db = z(n, d.in_feat), z(d.out_feat, d.in_feat), z(d.out_feat)
+        dlat = z(n, d.lat_feat) if ctx.mod else None
+        dwl = z(2 * d.out_feat, d.lat_feat) if ctx.mod else None
+        dbl = z(2 * d.out_feat) if ctx.mod else None
+        g32 = gout.detach().to(torch.float32).contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.cinema_sine_layer_backward(C.byref(d), _lib.ptr(ctx.w32), n, _lib.ptr(ctx.work), _lib.ptr(g32), _lib.ptr(dx),
+                                                  _lib.ptr(dlat), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dwl), _lib.ptr(dbl), stream),
+                   "cinema_sine_layer_backward")
+        return None, dx, dlat, dw, db, dwl, dbl

@@ -29,7 +29,9 @@ class SineLayer(nn.Module):
     linear: Linear(in_feat, out_feat); linear_lats: Linear(lat_feat, 2*out_feat) when modulated.
     Initialisation follows models/siren.py:17-24.  The arithmetic of the layer,
         sin(omega * z)            or   sin(omega * z * s + t),  [s | t] = linear_lats(latent),
-    is executed fused inside `Siren.forward`; a stand-alone call is not part of the hot path.
+    is executed fused inside `Siren.forward`; a stand-alone call `layer((x, latent)) -> (out, latent)` runs the same
+    layer kernels through cinema_sine_layer_forward / _backward (fp32 rows in and out; GEMM arithmetic per
+    `precision`: 'bf16' / 'fp32' / None = engine default).
     """
 
     def __init__(self, in_feat, lat_feat, out_feat, bias=True, is_first=False, omega=30):
@@ -49,10 +51,31 @@ class SineLayer(nn.Module):
         with torch.no_grad():
             self.linear.weight.uniform_(-bound, bound)
 
+    precision = None
+
     def forward(self, input):
-        raise NotImplementedError(
-            "cinema_amd.models.siren.SineLayer holds parameters only; its arithmetic runs fused inside Siren.forward "
-            "(HIP kernels). Call the enclosing Siren / INR_Decoder.")
+        """models/siren.py:26-36: (x (..., in_feat), latent (..., lat_feat)) -> (out (..., out_feat), latent)."""
+        from ..functions import SineLayerFunction
+        x, latent = input
+        if not x.is_cuda:
+            raise RuntimeError("cinema_amd SineLayer.forward runs HIP kernels: the input must live on the GPU")
+        prec = self.precision
+        if isinstance(prec, str):
+            prec = _lib.PREC_BF16 if prec.lower() in ("bf16", "bfloat16") else _lib.PREC_F32
+        if prec is None:
+            prec = E.default_precision()
+        lat_feat = self.linear_lats.in_features if self.linear_lats is not None else 0
+        desc = _lib.SineLayerDesc(self.in_features, lat_feat, self.out_features, prec, float(self.omega))
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.in_features)
+        if x2.shape[0] == 0:
+            return x.new_zeros(lead + (self.out_features,)), latent
+        if lat_feat:
+            out = SineLayerFunction.apply(desc, x2, latent.reshape(-1, lat_feat), self.linear.weight, self.linear.bias,
+                                          self.linear_lats.weight, self.linear_lats.bias)
+        else:
+            out = SineLayerFunction.apply(desc, x2, None, self.linear.weight, self.linear.bias, None, None)
+        return out.reshape(lead + (self.out_features,)), latent
 
 
 class Siren(nn.Module):

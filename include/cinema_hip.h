@@ -128,6 +128,27 @@ int cinema_siren_forward(const cinema_siren_desc *d /* host */, const float *par
                          const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
                          float *out, void *stream);
 
+/* One SineLayer on its own -- SineLayer.forward((x, latent)) -> (out, latent), models/siren.py:26-36:
+ *   z = linear(x);  out = sin(omega * z)                      (lat_feat == 0)
+ *   [s | t] = linear_lats(latent);  out = sin(omega * z * s + t)   (lat_feat > 0)
+ * through the same layer kernels the layer-by-layer stack uses.  All pointers are device fp32, dense row-major:
+ * x [N x in_feat], latent [N x lat_feat], W [out_feat x in_feat], b [out_feat], Wl [2 out_feat x lat_feat], bl [2 out_feat],
+ * out [N x out_feat].  precision selects the arithmetic of the GEMMs (bf16 operands with fp32 accumulation, or fp32).
+ * in_feat <= 3 runs the first-layer (coordinate) kernels, larger inputs the MFMA ones; out_feat must be a multiple of 16.
+ * work: cinema_sine_layer_work_bytes(d, N) bytes of device memory (padded operands, packed weights, what the backward
+ * needs); the backward call must see the work buffer of the forward call it differentiates, with W unchanged. */
+typedef struct cinema_sine_layer_desc {
+  int32_t in_feat, lat_feat, out_feat, precision;
+  float omega;
+} cinema_sine_layer_desc;
+int64_t cinema_sine_layer_work_bytes(const cinema_sine_layer_desc *d, int64_t N);
+int cinema_sine_layer_forward(const cinema_sine_layer_desc *d, const float *x, const float *latent, const float *W,
+                              const float *b, const float *Wl, const float *bl, int64_t N, void *work, float *out, void *stream);
+/* What autograd does for siren.py:26-36: dout [N x out_feat] -> dx [N x in_feat], dlatent [N x lat_feat], dW, db, dWl, dbl
+ * (shapes of W, b, Wl, bl; overwritten, not accumulated). */
+int cinema_sine_layer_backward(const cinema_sine_layer_desc *d, const float *W, int64_t N, void *work, const float *dout,
+                               float *dx, float *dlatent, float *dW, float *db, float *dWl, float *dbl, void *stream);
+
 /* Backward of the above (what autograd does for siren.py:26-36,59-61).
  * dout [Npad x out_dim] fp32 (rows >= N must be zero), gbuf [n_gbuf x Npad x HP] T scratch followed (at the next
  * multiple of 256 bytes) by gb_extra_bytes more bytes,
