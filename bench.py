@@ -45,60 +45,210 @@ def flops_per_sample(hidden=512, lat=256, layers=5, n_mod=3, out=12, in_dim=3):
     return 2 * mac, 6 * mac
 
 
-def cpu_baseline(args, n_samples, n_subjects, budget_s=25.0):
-    """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores."""
+def cpu_baseline(args, trainer, n_samples, lat0, tf0, flat0, budget_s=25.0):
+    """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores, on the
+    bench's own first batch: the store's coordinates, subject ids and sampled targets, the trainer's initial parameters.
+    All host threads first, then ONE thread on a quarter of the batch (SURVEY.md section 8d asks for both)."""
     from oracle import cinema_oracle as O
     a = args["inr_decoder"]
-    g = torch.Generator().manual_seed(42)
-    params = O.init_siren_params(3, a["latent_dim"][0], sum(a["out_dim"]), a["hidden_size"], a["num_hidden_layers"], 30, 30,
-                                 a["modulated_layers"], g)
-    for p in params.values():
-        p.requires_grad_(True)
-    lat = (torch.randn(n_subjects, *a["latent_dim"], generator=g) * 0.01).requires_grad_(True)
-    tft = torch.zeros(n_subjects, 6, requires_grad=True)
-    coords = torch.rand(n_samples, 3, generator=g) * 1.6 - 0.8
-    idx = torch.randint(0, n_subjects, (n_samples,), generator=g)
-    target = torch.cat((torch.rand(n_samples, 2, generator=g), torch.randint(1, 10, (n_samples, 1), generator=g).float()), 1)
+    st = trainer.store
+    n = n_samples
+    coords, subj = st.coords[:n].cpu(), st.subj[:n].cpu().long()
+    base = st.subj[:n].long() * st.V + st.voxel[:n]
+    target = torch.cat((st.intens[base], st.labels[base].float().unsqueeze(1)), 1).cpu()
+    params = {k: v.clone().requires_grad_(True) for k, v in trainer.eng.param_views(flat0).items()}
+    lat, tft = lat0.clone().requires_grad_(True), tf0.clone().requires_grad_(True)
     cfg = dict(num_hidden_layers=a["num_hidden_layers"], omega=[30, 30], sr_dims=2, loss_metric=args["optimizer"]["loss_metric"],
                class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0)
+
+    def timed(m, max_iters, budget):
+        times, t_start = [], time.time()
+        for it in range(max_iters):
+            for p in list(params.values()) + [lat, tft]:
+                p.grad = None
+            t0 = time.time()
+            O.training_step(params, lat, tft, coords[:m], target[:m], subj[:m], None, cfg)
+            if it > 0:
+                times.append(time.time() - t0)
+            if time.time() - t_start > budget and len(times) >= 1:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
     cores = torch.get_num_threads()
-    times = []
-    t_start = time.time()
-    for it in range(6):
-        for p in list(params.values()) + [lat, tft]:
-            p.grad = None
-        t0 = time.time()
-        O.training_step(params, lat, tft, coords, target, idx, None, cfg)
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_start > budget_s and len(times) >= 2:
-            break
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": n_samples / med, "unit": "coord samples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed fwd+loss+bwd steps (after 1 warm-up) of the CPU oracle at the same shape: "
-                      f"N={n_samples}, S={n_subjects}, fp32, torch CPU ops, median"}
+    med, k = timed(n, 6, budget_s * 0.6)
+    torch.set_num_threads(1)
+    m1 = max(n // 4, 1)
+    med1, k1 = timed(m1, 3, budget_s * 0.4)
+    torch.set_num_threads(cores)
+    return {"value": n / med, "unit": "coord samples/s", "cores": cores, "kind": "port",
+            "sample": f"{k} timed fwd+loss+bwd steps (after 1 warm-up) of the CPU oracle on the bench's first batch "
+                      f"(N={n}, S={lat0.shape[0]}, fp32, torch CPU ops, median)",
+            "one_thread": {"value": m1 / med1, "cores": 1, "sample": f"{k1} timed step(s) on the first {m1} samples of that batch"}}
+
+
+PMC_FILES = {"FETCH_SIZE": "r02_pmc_fetch.txt", "WRITE_SIZE": "r02_pmc_write.txt"}
 
 
 def pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
-    (profiles/r01f_pmc_fetch.txt, _write.txt: separate --pmc runs of this script, tools/profile_round.sh).  Counters
-    are in KiB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on
-    gfx950 (128-B requests tallied at 64 B), WRITE_SIZE is exact.  A live run cannot collect counters on itself, so
-    this is the profile of the same command, not of this process; (None, None) when the files are absent."""
-    here = os.path.dirname(os.path.abspath(__file__))
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload (profiles/r02_pmc_*:
+    separate --pmc runs of `bench.py --profile-step`, tools/profile_round.sh).  Counters are in KiB; FETCH_SIZE is doubled
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (128-B requests tallied at
+    64 B), WRITE_SIZE is exact.  A live run cannot collect counters on itself, so this is the profile of the same
+    command, not of this process; None when the files are absent."""
     vals = {}
-    for key, name in (("FETCH_SIZE", "r01f_pmc_fetch.txt"), ("WRITE_SIZE", "r01f_pmc_write.txt")):
-        path = os.path.join(here, "profiles", name)
+    for key, name in PMC_FILES.items():
+        path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
-            return None, None
+            return None
         for line in open(path):
             if line.startswith(kernel) and key + "=" in line:
                 vals[key] = float(line.split(key + "=")[1].split()[0])
     if len(vals) != 2:
-        return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01f_pmc_fetch.txt (x2) + profiles/r01f_pmc_write.txt"
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def event_ms(fn, reps):
+    """Average duration of fn() over `reps` back-to-back calls, HIP events on the stream the kernels are launched on
+    (the library launches on torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def box_peaks(dev):
+    """What this box reaches with library code, beside the vendor peaks: a large bf16 GEMM through hipBLASLt (torch.matmul)
+    and a 1 GiB device-to-device copy (read + write bytes)."""
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    ms = event_ms(lambda: torch.matmul(a, b), 10)
+    src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    dst = torch.empty_like(src)
+    ms_c = event_ms(lambda: dst.copy_(src), 10)
+    return {"mfma_bf16_tflops_measured": 2.0 * 8192 ** 3 / (ms * 1e-3) / 1e12, "mfma_probe": "torch.matmul bf16 8192^3 (hipBLASLt)",
+            "stream_copy_gbs_measured": 2.0 * src.numel() * 4 / (ms_c * 1e-3) / 1e9, "stream_probe": "1 GiB device-to-device copy, read + write"}
+
+
+def rooflines(trainer, n, opt, peak):
+    """Per-kernel rooflines of one training step.  SIREN kernels against the MFMA peak with the
+    ALGORITHMIC flops of the layer they compute (not the flops executed: padding and the per-sample linear_lats GEMM count
+    as the reference's), K1 / K3 against HBM with the compulsory bytes per sample.  Each kernel timed alone, `reps`
+    launches back to back."""
+    from cinema_amd import _lib
+    from cinema_amd import engine as E
+    eng, st = trainer.eng, trainer.store
+    ws, d, reps = eng.ws, eng.desc, opt.kernel_reps
+    H, L, nl, od, ind = d.hidden, d.lat, d.n_layers - 1, d.out_dim, d.in_dim
+    n_mod = bin(d.modulated_mask).count("1")
+    mac_main, mac_mod, mac_fin, mac_first = nl * H * H, n_mod * L * 2 * H, (H + L) * od, ind * H
+    mac_fwd = mac_first + mac_main + mac_mod + mac_fin
+    bf16 = opt.precision == "bf16"
+    coords, voxel, subj = st.coords[:n], st.voxel[:n], st.subj[:n]
+    tfs, lat = trainer.tfs.data, trainer.latents.data
+    names = {"fwd": "k_fused_fwd", "chain": "k_fused_bwd", "dlat": "k_dlat256", "dw": "k_dw256"} if bf16 else \
+        {"fwd": "k_layer_fwd x layers + k_final_fwd", "chain": "k_layer_bwd x layers", "dlat": "k_dlat", "dw": "k_dw_grouped"}
+    siren = [
+        ("fwd", "forward stack incl. final_linear", 2 * mac_fwd, lambda: eng.forward(n)),
+        ("chain", "backward chain: dX of every layer", 2 * (mac_main + mac_first + H * od),
+         lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)),
+        ("dlat", "d-latent GEMM", 2 * (mac_mod + L * od), lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DLAT)),
+        ("dw", "all weight-gradient GEMMs" + (" (+ split reduction)" if bf16 else ""), 2 * mac_fwd,
+         lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW)),
+    ]
+    objs, tot_ms, tot_fl = [], 0.0, 0.0
+    for key, what, fl, fn in siren:
+        ms = event_ms(fn, reps)
+        ach = n * fl / (ms * 1e-3) / 1e12
+        objs.append({"kernel": f"{names[key]} ({what})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": pmc_traffic(names[key]) if bf16 and n == 25000 else None,
+                     "avg_launch_ms": ms, "flop_per_sample": fl})
+        tot_ms += ms
+        tot_fl += n * fl
+    objs.sort(key=lambda o: -o["avg_launch_ms"])
+    agg = tot_fl / (tot_ms * 1e-3) / 1e12
+    siren_total = {"kernels": "SIREN fwd + bwd (the four above)", "flop_per_sample": 6 * mac_fwd, "ms": tot_ms,
+                   "achieved": agg, "peak": peak, "unit": "TFLOP/s", "frac": agg / peak}
+    # HBM view of the dominant kernel: the bytes are the saved-activation traffic this design chose, not compulsory ones
+    esize = 2 if bf16 else 4
+    chain = next(o for o in objs if o["kernel"].startswith(names["chain"]))
+    tensors = 2 * d.n_layers + 4 * n_mod                            # c + dz per layer; z, s, ds, dt per modulated layer
+    bps = tensors * d.HP * esize + 4 * (od + 2 * ind)
+    hbm_view = {"kernel": chain["kernel"], "bound": "hbm", "bytes": "saved-activation traffic of this design",
+                "achieved": n * bps / (chain["avg_launch_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bytes_per_sample": bps, "traffic": chain["traffic"]}
+    hbm_view["frac"] = hbm_view["achieved"] / HBM_PEAK_GBS
+    # K1 / K3: compulsory bytes per sample (SURVEY.md section 8d; the interpolated latent leaves K1 in the activation dtype)
+    cl = d.lat * esize
+    grouped = st.group_chunk > 0
+    k1f = (lambda: E.k1_forward_sorted(eng, coords, subj, lat, None, tfs, n)) if grouped and E.k1_sorted_eligible(tuple(lat.shape), d.LP) \
+        else (lambda: E.k1_forward(eng, trainer.k1, coords, subj, lat, None, tfs, False, n))
+    k1b = lambda: E.k1_backward(eng, trainer.k1, coords, subj, tuple(lat.shape), 0, tfs, False, n, want_latents=True,
+                                want_cond=False, dtf_out=trainer.tf_grad, dlat_out=trainer.lat_grad, grouped=grouped)
+    k3 = lambda: E.sample_loss(None, ws.out, n, trainer.sr_dims, trainer.n_cls, trainer.loss_metric, trainer.class_w, 1.0, 1.0,
+                               ws.dout, trainer.sums, voxel=voxel, subj=subj, intens=st.intens, labels=st.labels,
+                               voxels_per_subject=st.V, prepared=True)
+    E.k1_shadow(eng, trainer.k1, lat)
+    hbm = []
+    for name, bytes_ps, fn in (("K1 forward (affine + trilinear gather)", 12 + 4 + cl, k1f),
+                               ("K1 backward (coordinate gradient + latent / tf reductions)", 4 * d.lat + 12 + 4, k1b),
+                               ("K3 (ground-truth sampling + loss + dOut)", 4 * od + 4 * trainer.sr_dims + 1 + 4 + 4 * od + 1, k3)):
+        ms = event_ms(fn, reps)
+        ach = n * bytes_ps / (ms * 1e-3) / 1e9
+        hbm.append({"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "avg_launch_ms": ms, "bytes_per_sample": bytes_ps})
+    trainer.lat_grad.zero_()
+    trainer.tf_grad.zero_()
+    return objs, siren_total, hbm_view, hbm
+
+
+def run_atlas(opt, dev):
+    """BASELINE config 4 (cfg-A): one dense 310^3 volume (29.8 M coordinates at 0.5 mm) through INR_Decoder.inference."""
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import generate_world_grid
+    args = make_args(512, opt.precision, opt.loss, opt.n_samples)
+    sp = 155.0 / opt.grid
+    args["atlas_gen"] = {"spacing": [sp, sp, sp]}
+    args["device"] = str(dev)
+    torch.manual_seed(42)
+    dec = INR_Decoder(args, str(dev)).to(dev)
+    lat = torch.randn(1, 256, 3, 3, 3, device=dev) * 0.01
+    cond = torch.zeros(0, device=dev)
+    grid, shape, _ = generate_world_grid(args, device=dev, lazy=True)
+    G = len(grid)
+    for _ in range(opt.warmup):
+        vol = dec.inference(grid, lat, cond, shape, None, step_size=opt.chunk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        vol = dec.inference(grid, lat, cond, shape, None, step_size=opt.chunk)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert tuple(vol.shape) == (shape[0], shape[1], shape[2], 13) and bool(torch.isfinite(vol[..., 2:]).all())
+    eng = dec.sr_net.hot_state(dev).engine
+    m = min(opt.chunk, G)
+    ms = event_ms(lambda: eng.forward(m, keep=False), opt.kernel_reps)
+    fwd_f, _ = flops_per_sample()
+    peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+    ach = m * fwd_f / (ms * 1e-3) / 1e12
+    value = opt.steps * G / elapsed
+    res = {"metric": "atlas coords/sec, dense inference (hidden 512)", "value": value, "unit": "coords/s", "n_gpus": 1,
+           "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic",
+           "config": {"workload": f"cfg-A: one {shape[0]}x{shape[1]}x{shape[2]} volume ({G:,} coordinates, spacing {sp:.3f} mm) "
+                                  f"through INR_Decoder.inference in chunks of {opt.chunk}: grid coordinates made per chunk, "
+                                  "K1, SIREN forward (nothing kept), fused clamp / min-max / argmax / softmax epilogue, rescale"},
+           "end_to_end_mfma_tflops": value * fwd_f / 1e12, "end_to_end_mfma_frac": value * fwd_f / 1e12 / peak,
+           "roofline": {"kernel": "k_fused_fwd, nothing kept (one chunk)" if opt.precision == "bf16" else "k_layer_fwd x layers",
+                        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "avg_launch_ms": ms, "flop_per_sample": fwd_f}}
+    print(json.dumps(res))
 
 
 def main():
@@ -113,6 +263,11 @@ def main():
     ap.add_argument("--loss", default="mse", choices=["mse", "l1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--mode", default="train", choices=["train", "atlas"],
+                    help="train: the headline training step (default); atlas: one dense 310^3 volume through inference (cfg-A)")
+    ap.add_argument("--chunk", type=int, default=100000, help="atlas mode: coordinates per chunk (reference default step_size)")
+    ap.add_argument("--profile-step", action="store_true",
+                    help="only the timed steps: no per-kernel timing, no box probes, no CPU baseline (for rocprofv3 passes)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank dry run on a 1-GPU box: every rank uses cuda:0 and the gradient travels over gloo "
                          "(checks the rank logic; the number it prints is not a result)")
@@ -152,6 +307,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if opt.mode == "atlas":
+        if world > 1:
+            raise SystemExit("bench.py --mode atlas runs on one GPU (volumes shard over ranks as replicas, cinema_amd/atlas.py)")
+        if opt.steps == 50 and opt.warmup == 10:      # the training defaults: a volume is 1 200 training batches
+            opt.steps, opt.warmup = 3, 1
+        return run_atlas(opt, dev)
+
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
     args = make_args(512, opt.precision, opt.loss, opt.n_samples)
     torch.manual_seed(42)           # identical MLP init on every rank (replicated weights)
@@ -165,6 +327,7 @@ def main():
         print(f"[bench] synthetic store: {opt.subjects} subjects x {opt.grid}^3, {len(store):,} foreground samples/rank, "
               f"{time.time() - t0:.1f}s", file=sys.stderr)
     trainer = HotPathTrainer(args, store, dev)
+    lat0, tf0, flat0 = trainer.latents.detach().cpu().clone(), trainer.tfs.detach().cpu().clone(), trainer.eng.flat.detach().cpu().clone()
     n = opt.n_samples
     total_steps = opt.warmup + opt.steps
     if total_steps * n > len(store):
@@ -189,53 +352,15 @@ def main():
         elapsed = float(t.item())
     losses = trainer.loss_dict()
 
-    # ---- roofline of the dominant kernel, timed alone with events on its launch stream.  By time (profiles/) that is the
-    # fused backward chain k_fused_bwd: per sample it reads the saved c of every sine layer and z, s of the modulated
-    # ones and writes dz of every layer and ds, dt of the modulated ones, HP bf16 values each; its MFMA work
-    # (2*H*H*(L) FLOP per sample) would take a third of that at peak, so HBM is the roofline that binds it.
-    roofline = None
-    others = []
-    if rank == 0:
-        from cinema_amd import _lib
-        eng = trainer.eng
-        ws = eng.ws
-        reps = opt.kernel_reps
-        d = eng.desc
-        esize = 2 if opt.precision == "bf16" else 4
-
-        def time_phase(phase):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            eng.backward(n, ws.dout, weight_grads=True, phases=phase)
-            torch.cuda.synchronize()
-            ev0.record()
-            for _ in range(reps):
-                eng.backward(n, ws.dout, weight_grads=True, phases=phase)
-            ev1.record()
-            torch.cuda.synchronize()
-            return ev0.elapsed_time(ev1) / reps
-
-        n_mod = bin(d.modulated_mask).count("1")
-        ms = time_phase(_lib.BWD_PHASE_CHAIN)
-        tensors = 2 * d.n_layers + 4 * n_mod                       # c + dz per layer, z, s, ds, dt per modulated layer
-        bytes_per_sample = tensors * d.HP * esize + 4 * (d.out_dim + 2 * d.in_dim)
-        ach = n * bytes_per_sample / (ms * 1e-3) / 1e9
-        kname = ("k_fused_bwd (backward chain of the SIREN stack, one launch)" if opt.precision == "bf16"
-                 else "k_layer_bwd x layers (backward chain, fp32 layer-by-layer kernels)")
-        traffic, traffic_src = pmc_traffic("k_fused_bwd") if opt.precision == "bf16" and n == 25000 else (None, None)
-        roofline = {"kernel": kname, "bound": "hbm",
-                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": traffic_src, "avg_launch_ms": ms, "bytes_per_launch": n * bytes_per_sample}
-        peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-        ms_dw = time_phase(_lib.BWD_PHASE_DW)
-        macs = n * (5 * d.hidden * d.hidden + 3 * 2 * d.hidden * d.lat)           # dW of 5 linear + 3 linear_lats
-        others.append({"kernel": "k_dw256 + k_dw256_reduce (all weight-gradient GEMMs: 256x256 tiles, split partials, reduce)", "bound": "mfma",
-                       "achieved": 2.0 * macs / (ms_dw * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                       "frac": 2.0 * macs / (ms_dw * 1e-3) / 1e12 / peak, "avg_launch_ms": ms_dw})
+    peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+    siren = siren_total = hbm_view = hbm = peaks = None
+    if rank == 0 and not opt.profile_step:
+        siren, siren_total, hbm_view, hbm = rooflines(trainer, n, opt, peak)
+        peaks = box_peaks(dev)
 
     fwd_f, tot_f = flops_per_sample()
     value = world * opt.steps * n / elapsed
     step_tflops = value * tot_f / 1e12
-    peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     res = {
         "metric": "coord samples/sec fwd+bwd (hidden 512)", "value": value, "unit": "coord samples/s", "n_gpus": world,
         "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
@@ -248,10 +373,15 @@ def main():
         "loss_last_step": losses,
     }
     if rank == 0:
-        res["roofline"] = roofline
-        res["roofline_other_kernels"] = others
-        if world == 1 and not opt.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args, n, opt.subjects)
+        if siren is not None:
+            res["roofline"] = siren[0]                       # the SIREN kernel with the longest launch, against MFMA
+            res["roofline_siren_kernels"] = siren[1:]
+            res["roofline_siren_fwd_bwd"] = siren_total
+            res["roofline_hbm_view"] = hbm_view
+            res["roofline_hbm_kernels"] = hbm
+            res["box_peaks"] = peaks
+        if world == 1 and not opt.no_cpu_baseline and not opt.profile_step:
+            res["cpu_baseline"] = cpu_baseline(args, trainer, n, lat0, tf0, flat0)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -98,6 +98,9 @@ SIGNATURES = {
     "cinema_sine_layer_backward": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cinema_infer_minmax": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_infer_finish": [_P, _I64, _I32, _I32, _P, _P, _P],
+    "cinema_infer_chunk": [_P, _I64, _I32, _I32, _P, _P, _P],
+    "cinema_infer_rescale": [_P, _I64, _I32, _I32, _P, _P],
+    "cinema_grid_coords": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
 }
 _RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64}
 

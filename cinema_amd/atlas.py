@@ -56,7 +56,7 @@ def mean_latent(args: dict, latents: torch.Tensor, condition_values: torch.Tenso
 def generate_subject_from_latent(decoder, args: dict, latent_vec, condition_vector, transformation=None, device=None):
     """build_atlas.py:128-137 (autocast is replaced by the decoder's own precision switch)."""
     device = device or args["device"]
-    grid_coords, grid_shape, _ = generate_world_grid(args, device=device)
+    grid_coords, grid_shape, _ = generate_world_grid(args, device=device, lazy=True)
     with torch.no_grad():
         return decoder.inference(grid_coords, latent_vec, condition_vector, grid_shape, transformation)
 
@@ -78,7 +78,7 @@ def generate_atlas(decoder, args: dict, latents: torch.Tensor, scan_age_values: 
     device = device or args["device"]
     rank, world = par.world_info(process_group)
     decoder.eval()
-    grid_coords, grid_shape, affine = generate_world_grid(args, device=device)
+    grid_coords, grid_shape, affine = generate_world_grid(args, device=device, lazy=True)
     temp_steps, condition_vectors, jobs = atlas_jobs(args)
     mine = set(par.shard_jobs(len(jobs), rank, world))
     volumes: Dict[Tuple[int, int], torch.Tensor] = {}

@@ -162,6 +162,73 @@ __global__ void k_infer_finish(const float *out, long G, int od, int sr, const f
   }
 }
 
+// chunked form of the two kernels above: one pass per chunk of network outputs writes the clamped intensities, argmax and
+// softmax straight into the volume rows and folds the chunk into the running min / max; k_infer_rescale then maps the
+// intensity channels of the finished volume with the whole-volume min / max (same formula, same rounding).
+template <int MAXC>
+__global__ __launch_bounds__(256) void k_infer_chunk(const float *out, long G, int od, int sr, float *minmax, float *vol) {
+  const int ncls = od - sr, vc = sr + 1 + ncls;
+  float mn[8], mxv[8];
+  for (int m = 0; m < 8; ++m) { mn[m] = 1.f; mxv[m] = 0.f; }
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < G; n += (long)gridDim.x * blockDim.x) {
+    const float *o = out + n * od;
+    float *v = vol + n * vc;
+    for (int m = 0; m < sr; ++m) {
+      const float x = fminf(fmaxf(o[m], 0.f), 1.f);
+      v[m] = x;
+      mn[m] = fminf(mn[m], x);
+      mxv[m] = fmaxf(mxv[m], x);
+    }
+    float lg[MAXC], mx = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      lg[j] = j < ncls ? o[sr + j] : -INFINITY;
+      if (lg[j] > mx) { mx = lg[j]; arg = j; }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { lg[j] = j < ncls ? expf(lg[j] - mx) : 0.f; se += lg[j]; }
+    v[sr] = (float)arg;
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < ncls) v[sr + 1 + j] = lg[j] * inv;
+  }
+  for (int m = 0; m < sr; ++m) {
+    float a = mn[m], b = mxv[m];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+      a = fminf(a, __shfl_xor(a, k, 64));
+      b = fmaxf(b, __shfl_xor(b, k, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(reinterpret_cast<unsigned int *>(minmax) + m, __float_as_uint(a));
+      atomicMax(reinterpret_cast<unsigned int *>(minmax) + sr + m, __float_as_uint(b));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_infer_rescale(float *vol, long G, int vc, int sr, const float *minmax) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < G * sr; e += (long)gridDim.x * blockDim.x) {
+    const long n = e / sr;
+    const int m = (int)(e - n * sr);
+    float *v = vol + n * vc + m;
+    *v = (*v - minmax[m]) / (minmax[sr + m] - minmax[m]);   // 0/0 -> NaN like the reference
+  }
+}
+
+// coordinates of a run of the dense evaluation grid, 'ij' (x slowest) flattening of three axis vectors
+__global__ __launch_bounds__(256) void k_grid_coords(const float *ax, const float *ay, const float *az, long ny, long nz,
+                                                     long start, long count, float *coords) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+    const long f = start + e, i = f / (ny * nz), r = f - i * ny * nz, j = r / nz, k = r - j * nz;
+    coords[3 * e + 0] = ax[i];
+    coords[3 * e + 1] = ay[j];
+    coords[3 * e + 2] = az[k];
+  }
+}
+
 }  // namespace
 
 static int sample_loss_impl(bool prepared, const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
@@ -247,6 +314,36 @@ extern "C" int cinema_infer_finish(const float *out, int64_t G, int32_t out_dim,
                  "cinema_infer_finish: bad argument");
   const unsigned grid = (unsigned)std::min<long>((G + 255) / 256, 8192);
   hipLaunchKernelGGL(k_infer_finish<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long)G, out_dim, sr_dims, minmax, vol);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_infer_chunk(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, float *minmax, float *vol,
+                                  void *stream) {
+  CINEMA_REQUIRE(out && minmax && vol && G >= 1 && sr_dims >= 1 && sr_dims <= 8 && out_dim > sr_dims && out_dim - sr_dims <= 16,
+                 "cinema_infer_chunk: bad argument");
+  const unsigned grid = (unsigned)std::min<long>((G + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_infer_chunk<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long)G, out_dim, sr_dims, minmax, vol);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_infer_rescale(float *vol, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax, void *stream) {
+  CINEMA_REQUIRE(vol && minmax && G >= 1 && sr_dims >= 1 && sr_dims <= 8 && out_dim > sr_dims, "cinema_infer_rescale: bad argument");
+  const unsigned grid = (unsigned)std::min<long>((G * sr_dims + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_infer_rescale, dim3(grid), dim3(256), 0, (hipStream_t)stream, vol, (long)G, out_dim + 1, sr_dims, minmax);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_grid_coords(const float *ax, const float *ay, const float *az, int64_t nx, int64_t ny, int64_t nz,
+                                  int64_t start, int64_t count, float *coords, void *stream) {
+  CINEMA_REQUIRE(ax && ay && az && coords && nx >= 1 && ny >= 1 && nz >= 1, "cinema_grid_coords: bad argument");
+  CINEMA_REQUIRE(start >= 0 && count >= 1 && start + count <= nx * ny * nz, "cinema_grid_coords: run [%ld, %ld) leaves the grid",
+                 (long)start, (long)(start + count));
+  const unsigned grid = (unsigned)std::min<long>((count + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_grid_coords, dim3(grid), dim3(256), 0, (hipStream_t)stream, ax, ay, az, (long)ny, (long)nz, (long)start,
+                     (long)count, coords);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

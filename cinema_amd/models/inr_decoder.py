@@ -99,30 +99,56 @@ class INR_Decoder(nn.Module):
 
     # ------------------------------------------------------------------------------------
     def inference(self, coords, latent_vec, condition_vec, img_shape, tfs=None, step_size=100000):
-        """Dense volume evaluation (reference: models/inr_decoder.py:38-62): chunked forward, then
-        clamp / per-modality whole-volume min-max / argmax / softmax / channel concat, all on the GPU.
-        Returns (X, Y, Z, sr_dims + 1 + n_cls) fp32."""
-        dev = coords.device
-        n = coords.shape[0]
-        output = torch.empty((n, self.out_dim), device=dev, dtype=torch.float32)
-        idx0 = torch.zeros(min(step_size, n), dtype=torch.int32, device=dev)
-        tf_row = None if tfs is None else tfs.reshape(1, -1)
-        cond = condition_vec.reshape(1, -1).to(dev)
-        with torch.no_grad():
-            for i in range(0, n, step_size):
-                c = coords[i:i + step_size]
-                m = c.shape[0]
-                cv = cond.expand(m, -1)
-                output[i:i + m] = self.forward(c, latent_vec, cv, tf_row, idcs_df=idx0[:m], tf_table=tfs is not None)
-        lib = _lib.load()
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        """Dense volume evaluation (reference: models/inr_decoder.py:38-62): chunks of `step_size` coordinates through
+        K1 + the SIREN stack (nothing kept), each chunk's clamp / argmax / softmax written straight into its rows of the
+        result and folded into the per-modality whole-volume min / max, one rescale pass at the end.  `coords` is the
+        (G, 3) tensor of the reference or a `utils.WorldGrid` (axis vectors; each chunk's coordinates are then made on the
+        GPU).  No (G, out_dim) intermediate.  Returns (X, Y, Z, sr_dims + 1 + n_cls) fp32."""
+        from ..utils import WorldGrid
+        lazy = isinstance(coords, WorldGrid)
+        dev = torch.device(coords.device)
+        n = len(coords) if lazy else coords.shape[0]
         sr = self.sr_dims
-        minmax = torch.cat((torch.ones(sr, device=dev), torch.zeros(sr, device=dev)))
-        vol = torch.empty((n, sr + 1 + (self.out_dim - sr)), device=dev, dtype=torch.float32)
-        _lib.check(lib.cinema_infer_minmax(_lib.ptr(output), n, self.out_dim, sr, _lib.ptr(minmax), stream),
-                   "cinema_infer_minmax")
-        _lib.check(lib.cinema_infer_finish(_lib.ptr(output), n, self.out_dim, sr, _lib.ptr(minmax), _lib.ptr(vol), stream),
-                   "cinema_infer_finish")
+        vc = self.out_dim + 1
+        if n == 0:
+            return torch.zeros(list(img_shape) + [vc], device=dev)
+        lib = _lib.load()
+        st = self.sr_net.hot_state(dev)
+        eng = st.engine
+        chunk = int(min(step_size, n))
+        with torch.no_grad():
+            table = self.modulator(latent_vec).detach().to(device=dev, dtype=torch.float32).contiguous()
+            if table.dim() != 5 or table.shape[0] != 1:
+                raise ValueError("inference: latent_vec must be one grid (1, C, lx, ly, lz)")
+            cond = condition_vec.reshape(1, -1).to(device=dev, dtype=torch.float32)
+            cond = cond.expand(chunk, -1).contiguous() if cond.shape[1] > 0 else None
+            tf_row = None if tfs is None else tfs.detach().reshape(1, -1).to(device=dev, dtype=torch.float32).contiguous()
+            idx0 = torch.zeros(chunk, dtype=torch.int32, device=dev)
+            eng.workspace(chunk)
+            eng.pack()
+            stream = eng.stream()
+            sorted_k1 = E.k1_sorted_eligible(tuple(table.shape), eng.desc.LP)
+            minmax = torch.cat((torch.ones(sr, device=dev), torch.zeros(sr, device=dev)))
+            vol = torch.empty((n, vc), device=dev, dtype=torch.float32)
+            cbuf = torch.empty((chunk, 3), device=dev, dtype=torch.float32) if lazy else None
+            for i in range(0, n, chunk):
+                m = min(chunk, n - i)
+                if lazy:
+                    ax, ay, az = coords.axes
+                    _lib.check(lib.cinema_grid_coords(_lib.ptr(ax), _lib.ptr(ay), _lib.ptr(az), coords.dims[0], coords.dims[1],
+                                                      coords.dims[2], i, m, _lib.ptr(cbuf), stream), "cinema_grid_coords")
+                    c = cbuf
+                else:
+                    c = coords[i:i + m].detach().to(torch.float32).contiguous()
+                if sorted_k1:
+                    E.k1_forward_sorted(eng, c, idx0, table, cond, tf_row, m)
+                else:
+                    E.k1_forward(eng, st.k1, c, idx0, table, cond, tf_row, False, m)
+                out = eng.forward(m, keep=False)
+                _lib.check(lib.cinema_infer_chunk(_lib.ptr(out), m, self.out_dim, sr, _lib.ptr(minmax), _lib.ptr(vol[i:i + m]),
+                                                  stream), "cinema_infer_chunk")
+            _lib.check(lib.cinema_infer_rescale(_lib.ptr(vol), n, self.out_dim, sr, _lib.ptr(minmax), stream),
+                       "cinema_infer_rescale")
         modalities_rec = vol.reshape(list(img_shape) + [-1])
         if self.args.get("mask_reconstruction", False):
             # models/inr_decoder.py:87-107 (largest central component + dilation on the host through scipy) is SURVEY.md

@@ -105,8 +105,27 @@ def generate_combinations(args_data, conditions, keys=None, idx=0, current=None,
     return combos
 
 
-def generate_world_grid(args, normed=True, device="cpu"):
-    """Dense evaluation grid, x-major ('ij') flattening.  Reference: utils.py:235-250."""
+class WorldGrid:
+    """The dense evaluation grid as its three axis vectors: `INR_Decoder.inference` makes each chunk's coordinates on the
+    GPU from these (cinema_grid_coords) instead of holding the (G, 3) meshgrid (357 MB at 310^3).  `shape` and `len()`
+    are those of the (G, 3) tensor it stands for; `materialize()` builds that tensor."""
+
+    def __init__(self, axes):
+        self.axes = [a.to(torch.float32).contiguous() for a in axes]
+        self.dims = [int(a.shape[0]) for a in self.axes]
+        self.shape = (self.dims[0] * self.dims[1] * self.dims[2], 3)
+        self.device = self.axes[0].device
+
+    def __len__(self):
+        return self.shape[0]
+
+    def materialize(self):
+        return torch.stack(torch.meshgrid(*self.axes, indexing="ij"), dim=-1).reshape(-1, 3)
+
+
+def generate_world_grid(args, normed=True, device="cpu", lazy=False):
+    """Dense evaluation grid, x-major ('ij') flattening.  Reference: utils.py:235-250.
+    lazy=True returns a WorldGrid (axis vectors only) in place of the (G, 3) tensor."""
     bbox = args["dataset"]["world_bbox"]
     sp = args["atlas_gen"]["spacing"]
     axes = []
@@ -114,9 +133,9 @@ def generate_world_grid(args, normed=True, device="cpu"):
         ax = torch.arange(0, b, s, device=device)
         axes.append(ax / b * 2 - 1 if normed else ax)
     shape = [int(a.shape[0]) for a in axes]
-    grid = torch.stack(torch.meshgrid(axes[0], axes[1], axes[2], indexing="ij"), dim=-1).reshape(-1, 3)
+    grid = WorldGrid(axes)
     affine = torch.diag(torch.tensor([sp[0], sp[1], sp[2], 1.0], device=device))
-    return grid, shape, affine
+    return (grid if lazy else grid.materialize()), shape, affine
 
 
 def normalize_intensities(values, norm_type):

@@ -366,6 +366,20 @@ int cinema_infer_minmax(const float *out, int64_t G, int32_t out_dim, int32_t sr
 int cinema_infer_finish(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax,
                         float *vol, void *stream);
 
+/* The same epilogue for a volume evaluated in chunks, without a whole-volume copy of the network outputs
+ * (models/inr_decoder.py:44-57 keeps the (G, out_dim) tensor; at 310^3 that is 1.43 GB): per chunk, cinema_infer_chunk
+ * writes the clamped intensities, argmax and softmax into the chunk's rows of vol [G x (out_dim + 1)] and folds the chunk
+ * into minmax (initialised as for cinema_infer_minmax); after the last chunk cinema_infer_rescale applies
+ * (x - min) / (max - min) to the intensity channels of the whole volume.  Results equal the two-pass calls bit for bit. */
+int cinema_infer_chunk(const float *out, int64_t G, int32_t out_dim, int32_t sr_dims, float *minmax, float *vol_rows,
+                       void *stream);
+int cinema_infer_rescale(float *vol, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax, void *stream);
+
+/* Coordinates [count x 3] of the run [start, start + count) of the dense evaluation grid, x-major flattening of the three
+ * axis vectors (utils.py:235-250 builds the whole meshgrid, 357 MB at 310^3; the chunked evaluation makes each run). */
+int cinema_grid_coords(const float *ax, const float *ay, const float *az, int64_t nx, int64_t ny, int64_t nz, int64_t start,
+                       int64_t count, float *coords, void *stream);
+
 /* -------------------------------------------------------------------------------------
  * Optimiser step: torch.optim.AdamW exactly as the reference configures it
  * (build_atlas.py:432-453: one group per parameter table, decoupled weight decay, no amsgrad),

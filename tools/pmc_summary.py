@@ -5,8 +5,9 @@ f = glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")
-    if not any(k in n for k in ("k_layer", "k_dw", "k_dlat", "k_final", "k_lat_reduce", "k_trilerp", "k_pack", "k_adamw", "k_fused",
-                                "k_sample_loss", "k_group", "k_tf_reduce", "k_affine")):
+    if n.startswith("void "):
+        n = n[5:]
+    if not n.startswith("k_"):          # every kernel of libcinema_hip.so is named k_*; torch / rocprim kernels are not
         continue
     agg[n[:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, c in agg.items():

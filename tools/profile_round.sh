@@ -1,13 +1,13 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r01f}
+O=$R/gpurun_out/${1:-r02}
 mkdir -p $O
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --profile-step > $O/kt.log 2>&1 || exit 1
 python3 $R/tools/step_timeline.py $O/kt 3 > $O/step_timeline.txt 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-reps 2 > $O/fetch.log 2>&1 || exit 2
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-reps 2 > $O/write.log 2>&1 || exit 3
-timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-reps 2 > $O/tcc.log 2>&1 || exit 4
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $O/sq -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-reps 2 > $O/sq.log 2>&1 || exit 5
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --profile-step > $O/fetch.log 2>&1 || exit 2
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --profile-step > $O/write.log 2>&1 || exit 3
+timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --profile-step > $O/tcc.log 2>&1 || exit 4
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $O/sq -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --profile-step > $O/sq.log 2>&1 || exit 5
 for p in fetch write tcc sq; do python3 $R/tools/pmc_summary.py $O/$p > $O/pmc_$p.txt 2>&1; rm -rf $O/$p; done
 rm -f $O/kt/kt_kernel_trace.csv
 head -40 $O/kt/kt_kernel_stats.csv | cut -c1-160 > $O/kernel_stats_top.csv
