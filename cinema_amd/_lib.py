@@ -70,10 +70,11 @@ SIGNATURES = {
     "cinema_latent_to_node_major": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_affine_trilerp_fwd": [_P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P,
                                   _I32, _P],
-    "cinema_affine_trilerp_fwd_sorted": [_P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P,
-                                         _I32, _P],
+    "cinema_affine_trilerp_fwd_sorted": [_P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P,
+                                         _P, _I32, _P],
+    "cinema_cond_table_bwd": [_P, _P, _I64, _I64, _I32, _P, _P],
     "cinema_step_head": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
-                         _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
+                         _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
     "cinema_affine_trilerp_bwd": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                   _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_noalloc": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,

@@ -713,9 +713,9 @@ static int fused_pack_impl(const cinema_siren_desc *d, const float *params, void
 extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params, void *packed, const float *coords,
                                 const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                                 int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
-                                int32_t cond_dims, float *coords_t, void *lat_out, float *shadow, float *dcoords,
-                                int64_t n_dcoords, float *sums, const int64_t *voxel, const uint8_t *labels, int64_t V,
-                                int32_t n_cls, const float *class_w, float *scratch, void *stream) {
+                                int32_t cond_dims, int32_t cond_by_subject, float *coords_t, void *lat_out, float *shadow,
+                                float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const uint8_t *labels,
+                                int64_t V, int32_t n_cls, const float *class_w, float *scratch, void *stream) {
   CINEMA_REQUIRE(d && params && packed && coords && idx && latents && coords_t && lat_out, "cinema_step_head: null argument");
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "cinema_step_head: needs the activation-stationary bf16 path (hidden <= 512)");
   CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_step_head: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
@@ -727,7 +727,7 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
   StepHeadArgs a = {};
   if (int rc = fused_pack_args(d, params, packed, a.ps, a.sd, a.g_ps, a.g_sd)) return rc;
   a.k1 = TriFwdSortedArgs{coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, d->LP, coords_t,
-                          lat_out};
+                          lat_out, cond_by_subject ? 1 : 0};
   a.g_k1 = (int)((Npad + TFS_CHUNK - 1) / TFS_CHUNK);
   // backward-only repacking: the transposed linear_lats copies of the d-latent GEMM (cinema_siren_pack_part(.., 2))
   int nj = 0;

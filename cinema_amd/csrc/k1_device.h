@@ -162,6 +162,7 @@ struct TriFwdSortedArgs {
   const float *coords; const int32_t *idx; const float *embed; int tf_dim; const float *latents; const float *cond;
   long N, Npad, S; int C, cond_dims, LP;
   float *coords_t; void *lat_out;
+  int cond_by_subject;   // cond is a per-subject table [S x cond_dims] (row = idx[n]) instead of per-sample rows [N x cond_dims]
 };
 #define TFS_CHUNK 64
 #define TFS_THREADS 256
@@ -270,7 +271,7 @@ __device__ __forceinline__ void trilerp_fwd_sorted_body(const TriFwdSortedArgs &
           *reinterpret_cast<float4 *>(orow + 4 * lane) = o;
         }
       }
-      for (int j = lane; j < a.cond_dims; j += 64) orow[C + j] = (T)a.cond[n * a.cond_dims + j];
+      for (int j = lane; j < a.cond_dims; j += 64) orow[C + j] = (T)a.cond[(a.cond_by_subject ? (long)s : n) * a.cond_dims + j];
       for (int j = C + a.cond_dims + lane; j < a.LP; j += 64) orow[j] = (T)0.f;
     }
     seg_lo = seg_hi;

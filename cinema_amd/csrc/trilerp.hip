@@ -547,7 +547,8 @@ extern "C" int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx
 extern "C" int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
                                                 const float *latents, const float *cond, int64_t N, int64_t Npad, int64_t S,
                                                 int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
-                                                int32_t precision, float *coords_t, void *lat_out, int32_t LP, void *stream) {
+                                                int32_t cond_by_subject, int32_t precision, float *coords_t, void *lat_out,
+                                                int32_t LP, void *stream) {
   CINEMA_REQUIRE(coords && idx && latents && coords_t && lat_out, "cinema_affine_trilerp_fwd_sorted: null argument");
   CINEMA_REQUIRE(N >= 1 && Npad >= N && S >= 1, "cinema_affine_trilerp_fwd_sorted: bad sizes N=%ld Npad=%ld S=%ld", (long)N, (long)Npad, (long)S);
   CINEMA_REQUIRE(lx == 3 && ly == 3 && lz == 3 && C >= 4 && C <= TFS_CMAX && C % 4 == 0 && LP % 4 == 0,
@@ -556,7 +557,8 @@ extern "C" int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32
   CINEMA_REQUIRE(embed == nullptr || tf_dim == 6 || tf_dim == 9 || tf_dim == 12, "tf embedding width %d unsupported (6, 9 or 12)", tf_dim);
   CINEMA_REQUIRE(cond_dims == 0 || cond != nullptr, "cond_dims %d but cond is null", cond_dims);
   CINEMA_REQUIRE(LP >= C + cond_dims, "LP %d < C + cond_dims = %d", LP, C + cond_dims);
-  TriFwdSortedArgs a = {coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, LP, coords_t, lat_out};
+  TriFwdSortedArgs a = {coords, idx, embed, tf_dim, latents, cond, (long)N, (long)Npad, (long)S, C, cond_dims, LP, coords_t, lat_out,
+                        cond_by_subject ? 1 : 0};
   const unsigned grid = (unsigned)((Npad + TFS_CHUNK - 1) / TFS_CHUNK);
   if (precision == CINEMA_PREC_BF16)
     hipLaunchKernelGGL((k_trilerp_fwd_sorted<bf16_t, 3, 3, 3>), dim3(grid), dim3(TFS_THREADS), 0, (hipStream_t)stream, a);
@@ -715,4 +717,35 @@ extern "C" int cinema_affine_trilerp_bwd_noalloc(const float *coords, const int3
   // hipMemsetAsync on `stream` first; the previous call's contents beyond that are never read.
   return trilerp_bwd_impl(false, coords, idx, embed, tf_dim, embed_per_sample, affine, shadow, coords_t, dlat, dcoords_t, N,
                           Npad, S, C, lx, ly, lz, cond_dims, LP, dlatents, dembed, dcond, work, stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// gradient of a per-subject condition table from the per-sample d cond rows of a batch sorted by subject
+// ----------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_cond_table_bwd(const int32_t *idx, const float *dcond, long N, int cond_dims, float *out) {
+  const int s = blockIdx.x;
+  // [lo, hi) = rows of subject s (idx non-decreasing): two lower bounds
+  auto lower = [&](int key) { long a = 0, b = N; while (a < b) { const long m = (a + b) >> 1; if (idx[m] < key) a = m + 1; else b = m; } return a; };
+  const long lo = lower(s), hi = lower(s + 1);
+  __shared__ float red[4];
+  for (int j = 0; j < cond_dims; ++j) {
+    float acc = 0.f;
+    for (long n = lo + threadIdx.x; n < hi; n += 256) acc += dcond[n * cond_dims + j];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(long)s * cond_dims + j] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int cinema_cond_table_bwd(const int32_t *idx_sorted, const float *dcond, int64_t N, int64_t S, int32_t cond_dims,
+                                     float *dtable, void *stream) {
+  CINEMA_REQUIRE(idx_sorted && dcond && dtable && N >= 1 && S >= 1 && cond_dims >= 1, "cinema_cond_table_bwd: bad argument");
+  hipLaunchKernelGGL(k_cond_table_bwd, dim3((unsigned)S), dim3(256), 0, (hipStream_t)stream, idx_sorted, dcond, (long)N, cond_dims, dtable);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
 }

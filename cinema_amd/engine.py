@@ -308,9 +308,10 @@ def k1_sorted_eligible(latents_shape, LP: int) -> bool:
 
 
 def k1_forward_sorted(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
-                      cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
+                      cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, cond_by_subject: bool = False):
     """k1_forward for a batch grouped by subject with a per-subject embedding table: one launch, reads the latent
-    table in its API layout (no shadow, no affine table).  Bit-identical outputs."""
+    table in its API layout (no shadow, no affine table).  Bit-identical outputs.
+    cond_by_subject: cond is the (S, cond_dims) table, rows picked by idx in the kernel (no host-side gather)."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents.shape
     cond_dims = 0 if cond is None else cond.shape[1]
@@ -319,13 +320,23 @@ def k1_forward_sorted(eng: SirenEngine, coords: torch.Tensor, idx: torch.Tensor,
     npad = round_up(n, ROW_ALIGN)
     check(lib.cinema_affine_trilerp_fwd_sorted(ptr(coords), ptr(idx), ptr(tfs), 0 if tfs is None else tfs.shape[1],
                                                ptr(latents), ptr(cond) if cond_dims else None, n, npad, S, Cc, lx, ly, lz,
-                                               cond_dims, d.precision, ptr(ws.coords_t), ptr(ws.lat), d.LP, eng.stream()),
+                                               cond_dims, 1 if cond_by_subject else 0, d.precision, ptr(ws.coords_t), ptr(ws.lat),
+                                               d.LP, eng.stream()),
           "cinema_affine_trilerp_fwd_sorted")
+
+
+def cond_table_grad(idx_sorted: torch.Tensor, dcond: torch.Tensor, n: int, out: torch.Tensor):
+    """out[s] = sum of dcond rows of subject s for a batch sorted by subject (the index_add_ of the reference's autograd
+    for conditions[idcs_df], build_atlas.py:74-75): one launch, ranges by binary search, no atomics."""
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+    check(lib.cinema_cond_table_bwd(ptr(idx_sorted), ptr(dcond), n, out.shape[0], out.shape[1], ptr(out), stream),
+          "cinema_cond_table_bwd")
 
 
 def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
               cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, prepare: Optional[dict] = None,
-              shadow: bool = True):
+              shadow: bool = True, cond_by_subject: bool = False):
     """eng.pack() + k1_forward_sorted (+ k1_shadow, + step_prepare) in ONE launch (cinema_step_head); the caller
     checked k1_sorted_eligible and eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use).
     prepare: dict(dcoords, sums, n_cls, class_w, voxel, labels, V, scratch) or None."""
@@ -343,7 +354,8 @@ def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: t
     dco = p.get("dcoords")
     check(lib.cinema_step_head(C.byref(d), ptr(eng.flat), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
                                0 if tfs is None else tfs.shape[1], ptr(latents), ptr(cond) if cond_dims else None, n, npad,
-                               S, Cc, lx, ly, lz, cond_dims, ptr(ws.coords_t), ptr(ws.lat), ptr(sh), ptr(dco),
+                               S, Cc, lx, ly, lz, cond_dims, 1 if cond_by_subject else 0, ptr(ws.coords_t), ptr(ws.lat), ptr(sh),
+                               ptr(dco),
                                0 if dco is None else dco.numel(), ptr(p.get("sums")), ptr(p.get("voxel")), ptr(p.get("labels")),
                                int(p.get("V", 0)), int(p.get("n_cls", 0)), ptr(p.get("class_w")), ptr(p.get("scratch")),
                                eng.stream()), "cinema_step_head")

@@ -143,6 +143,7 @@ class HotPathTrainer:
                     self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
         self.sums = torch.zeros(4, device=self.device)
         self.norm = torch.zeros(2, device=self.device)               # union-batch normaliser of a data-parallel rank
+        self.cond_grad = None
         # Grouped batches on the bf16 chain kernels need no second stream: everything in front of the forward is ONE
         # launch (cinema_step_head).  The fallback shapes keep the backward-only preparation (transposed linear_lats copies,
         # node-major shadow, per-step clearing + class-weight normaliser) on a side stream that joins before the loss
@@ -165,16 +166,17 @@ class HotPathTrainer:
         n = coords.shape[0]
         ws = eng.workspace(n)
         ws.ensure_backward()
-        cond = None
+        cond, cond_table = None, None
         if self.cond_dims:
-            table = self.cond_param.data if self.cond_param is not None else st.conditions
-            cond = table[subj.long()].contiguous()
+            cond_table = (self.cond_param.data if self.cond_param is not None else st.conditions).contiguous()
         tfs = self.tfs.data
         main = torch.cuda.current_stream(self.device)
         use_cw = self.class_w is not None and self.seg_weight > 0
         grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
         fast_k1 = grouped and E.k1_sorted_eligible(tuple(self.latents.shape), eng.desc.LP)
 
+        if cond_table is not None and not fast_k1:
+            cond = cond_table[subj.long()].contiguous()  # generic K1 entry: per-sample rows (the grouped one gathers in the kernel)
         one_head = fast_k1 and eng.can_skip_saved()      # grouped batch on the activation-stationary bf16 path
         # nodes path: FiLM modulation from per-subject node tables (conditions are per subject here)
         use_nodes = grouped and E.nodes_eligible(eng, tuple(self.latents.shape))
@@ -183,7 +185,7 @@ class HotPathTrainer:
 
         def k1_fwd():
             if fast_k1:
-                E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)
+                E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond_table, tfs, n, cond_by_subject=True)
             else:
                 E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
 
@@ -197,7 +199,7 @@ class HotPathTrainer:
         joined = True
         if one_head:
             # everything in front of the forward as ONE launch (cinema_step_head): no second stream, no join
-            E.step_head(eng, self.k1, coords, subj, self.latents.data, cond, tfs, n,
+            E.step_head(eng, self.k1, coords, subj, self.latents.data, cond_table, tfs, n, cond_by_subject=True,
                         prepare=dict(dcoords=ws.dcoords, sums=self.sums, n_cls=self.n_cls, class_w=self.class_w if use_cw else None,
                                      voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch))
         elif self.side is not None:
@@ -243,9 +245,7 @@ class HotPathTrainer:
         if want_tf:
             self.tfs.grad = self.tf_grad
         if self.cond_param is not None:
-            g = torch.zeros_like(self.cond_param)
-            g.index_add_(0, subj.long(), dcond)
-            self.cond_param.grad = g
+            self.cond_param.grad = self._cond_table_grad(subj, dcond, n, grouped)
         self.opt_local.step()
         if work is not None:
             work.wait()
@@ -254,6 +254,17 @@ class HotPathTrainer:
         if self.train_mlp and not self.keep_grads:
             eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
         self.n_last = n
+
+    def _cond_table_grad(self, subj, dcond, n: int, grouped: bool):
+        """d loss / d conditions_val: the per-sample rows summed per subject (in the kernel for grouped batches)."""
+        if self.cond_grad is None:
+            self.cond_grad = torch.zeros_like(self.cond_param)
+        if grouped:
+            E.cond_table_grad(subj, dcond, n, self.cond_grad)
+        else:
+            self.cond_grad.zero_()
+            self.cond_grad.index_add_(0, subj.long(), dcond[:n])
+        return self.cond_grad
 
     def _union_normaliser(self, n: int, use_cw: bool, prepared_on_main: bool):
         """Rank of several: {samples, class-weight sum} of the union batch / world (parallel.share_batch_normaliser_), as
@@ -280,12 +291,11 @@ class HotPathTrainer:
         cond = None
         if self.cond_dims:
             cond_tab = (self.cond_param.data if self.cond_param is not None else st.conditions).contiguous()
-            cond = cond_tab[subj.long()].contiguous()
         tfs = self.tfs.data
         use_cw = self.class_w is not None and self.seg_weight > 0
         nt = self.nodes
         eng.pack(4 | 2)
-        E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond, tfs, n)     # lat rows: the per-sample d-latent / dW GEMMs
+        E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond_tab, tfs, n, cond_by_subject=True)   # lat rows: d-latent / dW GEMMs
         E.node_weights(eng, nt, coords, subj, tuple(self.latents.shape), tfs, n)
         E.node_tables(eng, nt, self.latents.data, cond_tab)
         E.k1_shadow(eng, self.k1, self.latents.data)
@@ -314,9 +324,7 @@ class HotPathTrainer:
         if want_tf:
             self.tfs.grad = self.tf_grad
         if self.cond_param is not None:
-            g = torch.zeros_like(self.cond_param)
-            g.index_add_(0, subj.long(), dcond)
-            self.cond_param.grad = g
+            self.cond_param.grad = self._cond_table_grad(subj, dcond, n, True)
         self.opt_local.step()
         if work is not None:
             work.wait()

@@ -187,11 +187,13 @@ int cinema_affine_trilerp_fwd(const float *coords, const int32_t *idx, const flo
  * table: embed [S x tf_dim] (or NULL) and the latent table in its API layout (S, C, G) go in directly -- no affine
  * table, no node-major shadow.  64-sample chunks keep their subject's table in LDS; any idx order is computed
  * correctly, only a grouped one is fast.  3x3x3 grid, C <= 256, C % 4 == 0, LP % 4 == 0 (else: error, use the call
- * above).  Outputs are bit-identical to cinema_affine_from_embedding + cinema_affine_trilerp_fwd. */
+ * above).  Outputs are bit-identical to cinema_affine_from_embedding + cinema_affine_trilerp_fwd.
+ * cond_by_subject != 0: cond is the per-subject condition table [S x cond_dims] and a sample takes row idx[n] (the
+ * reference gathers conditions[idcs_df] on the host side of the call, build_atlas.py:74-75); 0: per-sample rows [N x cond_dims]. */
 int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
                                      const float *latents, const float *cond, int64_t N, int64_t Npad, int64_t S,
-                                     int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t precision,
-                                     float *coords_t, void *lat_out, int32_t LP, void *stream);
+                                     int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims, int32_t cond_by_subject,
+                                     int32_t precision, float *coords_t, void *lat_out, int32_t LP, void *stream);
 
 /* The head of a training step in ONE launch: cinema_siren_pack (both parts), cinema_affine_trilerp_fwd_sorted and,
  * optionally, cinema_latent_to_node_major (shadow != NULL; only the K1 backward reads the shadow) and cinema_step_prepare
@@ -199,10 +201,15 @@ int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, co
  * after the other on one stream, or with a 6-10 us join on two.  bf16 stacks on the activation-stationary path only
  * (hidden <= 512, `pk_fs >= 0` after planning) and the shapes cinema_affine_trilerp_fwd_sorted takes; LP and the
  * precision come from the descriptor.  Same bits as the separate calls. */
+/* Gradient of the per-subject condition table from the per-sample rows dcond [N x cond_dims] the backward calls leave, for
+ * a batch sorted by subject: dtable[s] = sum of the rows with idx == s (what autograd's index_add does for
+ * conditions[idcs_df], build_atlas.py:74-75).  One workgroup per subject, ranges by binary search, deterministic. */
+int cinema_cond_table_bwd(const int32_t *idx_sorted, const float *dcond, int64_t N, int64_t S, int32_t cond_dims, float *dtable,
+                          void *stream);
 int cinema_step_head(const cinema_siren_desc *d /* host */, const float *params, void *packed, const float *coords,
                      const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                      int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
-                     float *coords_t, void *lat_out, float *shadow, float *dcoords, int64_t n_dcoords, float *sums,
+                     int32_t cond_by_subject, float *coords_t, void *lat_out, float *shadow, float *dcoords, int64_t n_dcoords, float *sums,
                      const int64_t *voxel, const uint8_t *labels, int64_t V, int32_t n_cls, const float *class_w,
                      float *scratch, void *stream);
 

@@ -241,6 +241,16 @@ def test_oracle_parity_wide_latent_257():
     assert not bad, f"{bad}\nall: {errs}"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_oracle_parity_cfgV_full_shape(precision):
+    """BASELINE config 5 (cfg-V) at its real shape through the module API: latent 256 x 3^3 + 1 condition (lat 257,
+    LP 320), hidden 512, 5 hidden layers modulated 1/3/5, out 1 + 10, per-sample condition rows with gradient."""
+    errs = _oracle_case(N=5000, S=12, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], out_dim=[1, 10], cond=1,
+                        seed=47, precision=precision, tf_table=True)
+    bad = failing(errs, TOL[precision], L2_TOL[precision])
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 @pytest.mark.parametrize("n", [16400, 25000])
 def test_oracle_parity_mixed_chain_tiles(n):
     """bf16, batch between one and two chip fillings of 64-sample workgroups (256 CUs x 64 = 16 384): the chain kernels

@@ -312,6 +312,53 @@ def test_validation_split_step_matches_oracle(precision):
         assert rel_err(x.detach().cpu().numpy(), r.detach().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("split", ["train", "val"])
+def test_trainer_step_cfgV_full_shape(split):
+    """BASELINE config 5 (cfg-V) at its real shape: latent 256 x 3^3 + 1 condition (lat 257, LP 320), hidden 512, 5 hidden
+    layers modulated 1/3/5, out 1 + 10, cond_scale 0.12, bf16, batch grouped by subject (the per-subject condition table is
+    gathered inside K1; for split='val' its gradient is reduced per subject in cinema_cond_table_bwd).  Gradients == CPU
+    oracle, max-norm and L2."""
+    from oracle import cinema_oracle as O
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([256, 3, 3, 3], 512, 5, [1, 3, 5], [1, 10], 1, "bf16", tf_weight=0.0)
+    torch.manual_seed(55)
+    S, n = 12, 6000
+    store = SubjectStore.synthetic(S, (24, 24, 24), 155.0 / 24, [155, 155, 155], 1, 10, seed=19, device=DEV, cond_dims=1,
+                                   cond_scale=0.12)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(4), group_chunk=n)
+    tr = HotPathTrainer(args, store, DEV, split=split, keep_grads=True)
+    assert tr.eng.desc.lat == 257 and tr.eng.desc.LP == 320
+    with torch.no_grad():
+        tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(6)) - 0.5) * 0.05)
+        if split == "val":
+            tr.cond_param.copy_(torch.randn(tr.cond_param.shape, generator=torch.Generator().manual_seed(7)) * 0.05)
+    cond_tab = (tr.cond_param if split == "val" else store.conditions).detach().cpu().clone()
+    lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()
+    coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
+    base = subj.long() * store.V + voxel
+    target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
+    lat_o, tf_o, c_o = (x.clone().requires_grad_(True) for x in (lat0, tf0, cond_tab))
+    cfg = dict(num_hidden_layers=5, omega=[30, 30], sr_dims=1, loss_metric="mse",
+               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0,
+               seg_weight=0.0 if split == "val" else 1.0)
+    loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, c_o[subj.long()], cfg)
+    tr.step(0, n)
+    got = tr.loss_dict()
+    assert abs(got["total"] - float(loss_o["total"])) < 2e-2 * abs(float(loss_o["total"]))
+    errs = both_errs("glat", tr.lat_grad.cpu().numpy(), lat_o.grad.numpy())
+    errs.update(both_errs("gtf", tr.tf_grad.cpu().numpy(), tf_o.grad.numpy()))
+    if split == "val":
+        errs.update(both_errs("gcond", tr.cond_param.grad.cpu().numpy(), c_o.grad.numpy()))
+        assert torch.equal(tr.eng.flat.detach().cpu(), flat0)
+    else:
+        gviews = tr.eng.param_views(tr.eng.flat_grad.cpu())
+        for k, p in params.items():
+            errs.update(both_errs("g_" + k, gviews[k].numpy(), p.grad.numpy()))
+    bad = failing(errs, 2e-2, L2_TOL["bf16"])
+    assert not bad, bad
+
+
 def test_epoch_walks_the_whole_list_and_steps_the_schedule():
     """HotPathTrainer.epoch (build_atlas.py:65-68, 455-463): ceil(m / n_samples) steps including the ragged last one,
     every chunk grouped by subject (the grouped K1 kernels take them), cosine schedule stepped once per epoch."""
