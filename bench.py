@@ -233,7 +233,11 @@ def run_atlas(opt, dev):
     assert tuple(vol.shape) == (shape[0], shape[1], shape[2], 13) and bool(torch.isfinite(vol[..., 2:]).all())
     eng = dec.sr_net.hot_state(dev).engine
     m = min(opt.chunk, G)
-    ms = event_ms(lambda: eng.forward(m, keep=False), opt.kernel_reps)
+    from cinema_amd import engine as E
+    nodes = E.nodes_inference_eligible(eng, (1, 256, 3, 3, 3))
+    idx0 = torch.zeros(m, dtype=torch.int32, device=dev)
+    ms = event_ms((lambda: eng.forward_nodes(m, dec._nodes, idx0, keep=False)) if nodes else (lambda: eng.forward(m, keep=False)),
+                  opt.kernel_reps)
     fwd_f, _ = flops_per_sample()
     peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     ach = m * fwd_f / (ms * 1e-3) / 1e12
@@ -245,7 +249,7 @@ def run_atlas(opt, dev):
                                   f"through INR_Decoder.inference in chunks of {opt.chunk}: grid coordinates made per chunk, "
                                   "K1, SIREN forward (nothing kept), fused clamp / min-max / argmax / softmax epilogue, rescale"},
            "end_to_end_mfma_tflops": value * fwd_f / 1e12, "end_to_end_mfma_frac": value * fwd_f / 1e12 / peak,
-           "roofline": {"kernel": "k_fused_fwd, nothing kept (one chunk)" if opt.precision == "bf16" else "k_layer_fwd x layers",
+           "roofline": {"kernel": ("k_nodes_fwd" if nodes else "k_fused_fwd") + ", nothing kept (one chunk)" if opt.precision == "bf16" else "k_layer_fwd x layers",
                         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                         "avg_launch_ms": ms, "flop_per_sample": fwd_f}}
     print(json.dumps(res))

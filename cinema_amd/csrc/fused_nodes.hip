@@ -581,9 +581,9 @@ static inline int ksteps_h(int k) { return ((k / 32) + FUSED_RING - 1) / FUSED_R
 
 // Launch plan: `units` 16-sample tiles over workgroups of BIG or BIG - 1 tiles, ONE launch.  A workgroup's time is its
 // weight stream (independent of its sample count) plus the epilogues of its samples, so the plan aims at the fewest
-// chip fillings: cfg-D (1568 tiles, 256 CUs) = 32 workgroups of 7 tiles + 224 of 6, every CU streams the weights once.
+// chip fillings: measured at cfg-D: 4-tile workgroups (0 spills) beat 6/7-tile ones (fewer weight streams, but spills): default 4, CINEMA_NODES_BIG=4..7.
 static void nodes_launch_plan(int64_t Npad, int64_t S, int *big, int *g_big, int *g_small) {
-  static const int bigmax = [] { const char *e = getenv("CINEMA_NODES_BIG"); const int v = e ? atoi(e) : 7; return v < 4 ? 4 : (v > 7 ? 7 : v); }();
+  static const int bigmax = [] { const char *e = getenv("CINEMA_NODES_BIG"); const int v = e ? atoi(e) : 4; return v < 4 ? 4 : (v > 7 ? 7 : v); }();
   const long units = Npad / 16 + std::min<long>(S, Npad);      // upper bound of the tile count (cinema_node_tiles)
   const long ncu = cinema_cu_count();
   const long rounds = (units + bigmax * ncu - 1) / (bigmax * ncu);

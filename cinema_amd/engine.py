@@ -242,6 +242,13 @@ def nodes_eligible(eng: "SirenEngine", latents_shape) -> bool:
     return eng.can_skip_saved() and eng.desc.pk_ns >= 0 and lx * ly * lz <= 30 and os.environ.get("CINEMA_NODES", "0") == "1"
 
 
+def nodes_inference_eligible(eng: "SirenEngine", latents_shape) -> bool:
+    """Dense inference takes the nodes path by default where the shape allows (forward only, nothing kept: measured 24 %
+    faster than the per-sample forward at cfg-D); CINEMA_NODES=0 turns it off."""
+    _, _, lx, ly, lz = latents_shape
+    return eng.can_skip_saved() and eng.desc.pk_ns >= 0 and lx * ly * lz <= 30 and os.environ.get("CINEMA_NODES", "1") != "0"
+
+
 def node_weights(eng: "SirenEngine", nt: NodeTables, coords: torch.Tensor, idx: torch.Tensor, latents_shape,
                  tfs: Optional[torch.Tensor], n: int):
     """transform + interpolation weights into eng.ws.coords_t / nt.wrows (rows up to Npad)."""

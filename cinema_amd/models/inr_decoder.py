@@ -67,6 +67,7 @@ class INR_Decoder(nn.Module):
         self.sr_net = Siren(a["in_dim"], a["latent_dim"][0] + a["cond_dims"], self.out_dim, a["hidden_size"],
                             a["num_hidden_layers"], f_om=a["omega"][0], h_om=a["omega"][1], outermost_linear=True,
                             modulated_layers=a["modulated_layers"], precision=precision)
+        self._nodes = None           # node tables of the dense-inference path (engine.NodeTables), made on first use
 
     # ------------------------------------------------------------------------------------
     def forward(self, coords, latent_vecs, condition_vecs, tfs=None, idcs_df=None, tf_table: bool = False):
@@ -125,9 +126,17 @@ class INR_Decoder(nn.Module):
             tf_row = None if tfs is None else tfs.detach().reshape(1, -1).to(device=dev, dtype=torch.float32).contiguous()
             idx0 = torch.zeros(chunk, dtype=torch.int32, device=dev)
             eng.workspace(chunk)
-            eng.pack()
             stream = eng.stream()
             sorted_k1 = E.k1_sorted_eligible(tuple(table.shape), eng.desc.LP)
+            # one subject, so every chunk is "grouped": FiLM modulation from this volume's node projections (computed once)
+            nodes = E.nodes_inference_eligible(eng, tuple(table.shape))
+            if nodes:
+                eng.pack(4)
+                if self._nodes is None:
+                    self._nodes = E.NodeTables()
+                E.node_tables(eng, self._nodes, table, None if cond is None else cond[:1])
+            else:
+                eng.pack()
             minmax = torch.cat((torch.ones(sr, device=dev), torch.zeros(sr, device=dev)))
             vol = torch.empty((n, vc), device=dev, dtype=torch.float32)
             cbuf = torch.empty((chunk, 3), device=dev, dtype=torch.float32) if lazy else None
@@ -140,11 +149,15 @@ class INR_Decoder(nn.Module):
                     c = cbuf
                 else:
                     c = coords[i:i + m].detach().to(torch.float32).contiguous()
-                if sorted_k1:
+                if nodes:
+                    E.node_weights(eng, self._nodes, c, idx0, tuple(table.shape), tf_row, m)
+                    out = eng.forward_nodes(m, self._nodes, idx0, keep=False)
+                elif sorted_k1:
                     E.k1_forward_sorted(eng, c, idx0, table, cond, tf_row, m)
+                    out = eng.forward(m, keep=False)
                 else:
                     E.k1_forward(eng, st.k1, c, idx0, table, cond, tf_row, False, m)
-                out = eng.forward(m, keep=False)
+                    out = eng.forward(m, keep=False)
                 _lib.check(lib.cinema_infer_chunk(_lib.ptr(out), m, self.out_dim, sr, _lib.ptr(minmax), _lib.ptr(vol[i:i + m]),
                                                   stream), "cinema_infer_chunk")
             _lib.check(lib.cinema_infer_rescale(_lib.ptr(vol), n, self.out_dim, sr, _lib.ptr(minmax), stream),
