@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_bwd_coord_reduce(TriBwdArgs a, Dw256Arg
   else trilerp_bwd_coord_body(a, b - g_red, g_coord);
 }
 
+
 // ---- grouping of the samples by subject (counting sort) ----
 // Both passes privatise the per-subject counters in LDS (one global atomic per non-empty bin per block)
 // when the subject count fits; each block owns the contiguous sample range [beg, end).
@@ -443,13 +444,19 @@ __device__ __forceinline__ void dense_axis(const Axis &a, float (&w)[LX > LY ? (
     w[i] = i < L ? ((i == a.i0 ? a.w0 : 0.f) + ((i == a.i1 && a.i1 != a.i0) ? a.w1 : 0.f)) : 0.f;
 }
 
-#define LATRED_WAVES 8
+#define LATRED_WAVES 4     // 512 threads; LDS 27.6 KB (sums) + 28.7 KB (weights): two workgroups per CU, one round at cfg-D
+#define LATRED_CHUNK 256
 template <int LX, int LY, int LZ>
 __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedArgs a) {
   constexpr int G = LX * LY * LZ;
+  constexpr int GS = (G + 3) / 4 * 4;           // weight row stride: float4 broadcasts
   constexpr int LM = LX > LY ? (LX > LZ ? LX : LZ) : (LY > LZ ? LY : LZ);
-  // 2 * LATRED_WAVES waves walk the subject's samples; the upper half folds its sums into the lower half's LDS slots
+  // 2 * LATRED_WAVES waves walk the subject's samples; the upper half folds its sums into the lower half's LDS slots.
+  // The G dense interpolation weights of a sample are the same for every channel: one thread per sample computes them
+  // into LDS (chunks of LATRED_CHUNK samples), the walking waves read them back as broadcasts.
   __shared__ float part[LATRED_WAVES][G][64];
+  __shared__ __attribute__((aligned(16))) float wts[LATRED_CHUNK][GS];
+  __shared__ int sn[LATRED_CHUNK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long s = blockIdx.x;
   if (a.tf_dembed != nullptr && blockIdx.y == gridDim.y - 1) {        // workgroup-uniform
@@ -461,26 +468,47 @@ __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedA
   float acc[G];
 #pragma unroll
   for (int k = 0; k < G; ++k) acc[k] = 0.f;
-  // no store inside the loop: the unrolled iterations' dependent loads (perm -> coords, dlat) overlap
-#pragma unroll 4
-  for (int p = beg + wave; p < end; p += 2 * LATRED_WAVES) {
-    const long n = a.perm != nullptr ? a.perm[p] : p;
-    const Axis az = axis_nodes(a.coords_t[n * 3], LZ), ay = axis_nodes(a.coords_t[n * 3 + 1], LY),
-               ax = axis_nodes(a.coords_t[n * 3 + 2], LX);
-    const float v = c < a.C ? a.dlat[n * a.LP + c] : 0.f;
-    float wx[LM], wy[LM], wz[LM];
-    dense_axis<LX, LY, LZ>(ax, wx, LX);
-    dense_axis<LX, LY, LZ>(ay, wy, LY);
-    dense_axis<LX, LY, LZ>(az, wz, LZ);
+  for (int cb = beg; cb < end; cb += LATRED_CHUNK) {
+    const int cnt = end - cb < LATRED_CHUNK ? end - cb : LATRED_CHUNK;
+    __syncthreads();                              // the previous chunk's weights have been read
+    if ((int)threadIdx.x < cnt) {
+      const int p = cb + threadIdx.x;
+      const long n = a.perm != nullptr ? a.perm[p] : p;
+      const Axis az = axis_nodes(a.coords_t[n * 3], LZ), ay = axis_nodes(a.coords_t[n * 3 + 1], LY),
+                 ax = axis_nodes(a.coords_t[n * 3 + 2], LX);
+      float wx[LM], wy[LM], wz[LM];
+      dense_axis<LX, LY, LZ>(ax, wx, LX);
+      dense_axis<LX, LY, LZ>(ay, wy, LY);
+      dense_axis<LX, LY, LZ>(az, wz, LZ);
+      sn[threadIdx.x] = (int)n;
 #pragma unroll
-    for (int ix = 0; ix < LX; ++ix) {
-      const float vx = wx[ix] * v;
+      for (int ix = 0; ix < LX; ++ix)
 #pragma unroll
-      for (int iy = 0; iy < LY; ++iy) {
-        const float vxy = vx * wy[iy];
+        for (int iy = 0; iy < LY; ++iy)
 #pragma unroll
-        for (int iz = 0; iz < LZ; ++iz) acc[(ix * LY + iy) * LZ + iz] += vxy * wz[iz];
+          for (int iz = 0; iz < LZ; ++iz) wts[threadIdx.x][(ix * LY + iy) * LZ + iz] = wx[ix] * wy[iy] * wz[iz];
+    }
+    __syncthreads();
+    // all d-latent values of this wave's samples are requested first (one latency for the chunk), then folded in
+    constexpr int PER = LATRED_CHUNK / (2 * LATRED_WAVES);
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = wave + 2 * LATRED_WAVES * j;
+      v[j] = (t < cnt && c < a.C) ? a.dlat[(long)sn[t] * a.LP + c] : 0.f;
+    }
+#pragma unroll 2
+    for (int j = 0; j < PER; ++j) {
+      const int t = wave + 2 * LATRED_WAVES * j;
+      if (t >= cnt) break;
+      float w[GS];
+#pragma unroll
+      for (int k4 = 0; k4 < GS / 4; ++k4) {
+        const float4 q = *reinterpret_cast<const float4 *>(&wts[t][4 * k4]);
+        w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
       }
+#pragma unroll
+      for (int k = 0; k < G; ++k) acc[k] = __builtin_fmaf(w[k], v[j], acc[k]);
     }
   }
   if (wave < LATRED_WAVES) {
@@ -493,8 +521,9 @@ __global__ __launch_bounds__(128 * LATRED_WAVES) void k_lat_reduce_dense(LatRedA
     for (int k = 0; k < G; ++k) part[wave - LATRED_WAVES][k][lane] += acc[k];
   }
   __syncthreads();
+  // thread = (node, channel) with the channel fastest: conflict-free LDS reads
   for (int e = threadIdx.x; e < 64 * G; e += 128 * LATRED_WAVES) {
-    const int cc = e / G, nd = e - cc * G;
+    const int nd = e >> 6, cc = e & 63;
     if (c0 + cc < a.C) {
       float t = 0.f;
 #pragma unroll
