@@ -232,7 +232,7 @@ def run_atlas(opt, dev):
     elapsed = time.perf_counter() - t0
     assert tuple(vol.shape) == (shape[0], shape[1], shape[2], 13) and bool(torch.isfinite(vol[..., 2:]).all())
     eng = dec.sr_net.hot_state(dev).engine
-    m = min(opt.chunk, G)
+    m = min(max(opt.chunk, dec.min_inference_chunk), G)
     from cinema_amd import engine as E
     nodes = E.nodes_inference_eligible(eng, (1, 256, 3, 3, 3))
     idx0 = torch.zeros(m, dtype=torch.int32, device=dev)
@@ -246,7 +246,8 @@ def run_atlas(opt, dev):
            "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic",
            "config": {"workload": f"cfg-A: one {shape[0]}x{shape[1]}x{shape[2]} volume ({G:,} coordinates, spacing {sp:.3f} mm) "
-                                  f"through INR_Decoder.inference in chunks of {opt.chunk}: grid coordinates made per chunk, "
+                                  f"through INR_Decoder.inference(step_size={opt.chunk}), evaluated in chunks of "
+                                  f"{min(max(opt.chunk, dec.min_inference_chunk), G)}: grid coordinates made per chunk, "
                                   "K1, SIREN forward (nothing kept), fused clamp / min-max / argmax / softmax epilogue, rescale"},
            "end_to_end_mfma_tflops": value * fwd_f / 1e12, "end_to_end_mfma_frac": value * fwd_f / 1e12 / peak,
            "roofline": {"kernel": ("k_nodes_fwd" if nodes else "k_fused_fwd") + ", nothing kept (one chunk)" if opt.precision == "bf16" else "k_layer_fwd x layers",

@@ -355,6 +355,7 @@ def test_g10_inference_volume():
     dec = INR_Decoder(args, "cuda:0").to(dev())
     dec.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("p_")})
     coords, lat, cond, tf = (T(g[k]).to(dev()) for k in ("coords", "lat", "cond", "tf"))
+    dec.min_inference_chunk = 1          # keep step_size = 500 as the chunk: four chunks, the last one ragged
     vol = dec.inference(coords, lat, cond, [12, 12, 12], None, step_size=500).cpu().numpy()
     ref = g["vol"]
     assert vol.shape == ref.shape
@@ -365,6 +366,41 @@ def test_g10_inference_volume():
     assert np.abs(np.nan_to_num(vol[..., :2]) - np.nan_to_num(ref[..., :2])).max() < 1e-3      # min-max scaled intensities
     vol_tf = dec.inference(coords, lat, cond, [12, 12, 12], tf, step_size=500).cpu().numpy()
     assert np.abs(np.nan_to_num(vol_tf[..., 3:]) - np.nan_to_num(g["vol_tf"][..., 3:])).max() < 1e-4
+
+
+@pytest.mark.parametrize("cond_dims", [0, 1])
+def test_inference_nodes_path_matches_per_sample_path(cond_dims, monkeypatch):
+    """Dense inference on the bf16 activation-stationary stack takes the nodes path (FiLM modulation interpolated from the
+    volume's node projections); CINEMA_NODES=0 runs the per-sample forward.  Same volume within bf16 tolerance, from a
+    WorldGrid (coordinates made per chunk on the GPU) and from the explicit (G, 3) tensor, several ragged chunks, with a
+    transformation row."""
+    from cinema_amd import engine as E
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import generate_world_grid
+    args = make_args([64, 3, 3, 3], 256, 4, [1, 3], [2, 6], cond_dims, "bf16")
+    args["atlas_gen"] = {"spacing": [155.0 / 21, 155.0 / 19, 155.0 / 23]}
+    args["dataset"]["world_bbox"] = [155, 155, 155]
+    torch.manual_seed(5)
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    dec.min_inference_chunk = 1
+    lat = torch.randn(1, 64, 3, 3, 3, device=dev()) * 0.1
+    cond = torch.full((cond_dims,), 0.03, device=dev())
+    tf = (torch.rand(6, device=dev()) - 0.5) * 0.1
+    grid, shape, _ = generate_world_grid(args, device=dev(), lazy=True)
+    assert len(grid) == shape[0] * shape[1] * shape[2] and torch.equal(grid.materialize(), generate_world_grid(args, device=dev())[0])
+    assert E.nodes_inference_eligible(dec.sr_net.hot_state(dev()).engine, (1, 64, 3, 3, 3))
+    vol_n = dec.inference(grid, lat, cond, shape, tf, step_size=2000)
+    vol_t = dec.inference(grid.materialize(), lat, cond, shape, tf, step_size=2000)
+    # coordinates made on the GPU == the meshgrid's (a clamped-flat channel is 0/0 = NaN as in the reference)
+    assert torch.equal(torch.isnan(vol_n), torch.isnan(vol_t)) and torch.equal(torch.nan_to_num(vol_n), torch.nan_to_num(vol_t))
+    monkeypatch.setenv("CINEMA_NODES", "0")
+    vol_p = dec.inference(grid, lat, cond, shape, tf, step_size=2000)
+    assert vol_n.shape == (*shape, 2 + 1 + 6)
+    soft = (vol_n[..., 3:] - vol_p[..., 3:]).abs().max()
+    assert torch.equal(torch.isnan(vol_n), torch.isnan(vol_p))
+    inten = (torch.nan_to_num(vol_n[..., :2]) - torch.nan_to_num(vol_p[..., :2])).abs().max()
+    assert float(soft) < 2e-2 and float(inten) < 2e-2, (float(soft), float(inten))
+    assert float((vol_n[..., 2] != vol_p[..., 2]).float().mean()) < 2e-2      # argmax flips only where two classes tie
 
 
 def test_state_dict_roundtrip_and_deepcopy():
