@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void k_sample_loss(LossArgs a) {
     }
     if (a.target_out) a.target_out[n * tcols + a.sr_dims] = (float)y;
     if (a.seg_scale > 0.f) {
+      // a label outside [0, n_cls) makes torch's CrossEntropyLoss of the reference abort (device assert); here it
+      // poisons the sample's loss term and gradient row with NaN so that it cannot pass unnoticed
+      const bool bad_label = y < 0 || y >= a.n_cls;
       y = y < 0 ? 0 : (y >= a.n_cls ? a.n_cls - 1 : y);
       float lg[MAXC];
       float mx = -INFINITY;
@@ -85,9 +88,9 @@ __global__ __launch_bounds__(256) void k_sample_loss(LossArgs a) {
       ly = orow[a.sr_dims + y];
       const float lse = mx + logf(se);
       const float w = a.class_w ? a.class_w[y] : 1.f;
-      acc_ce += w * (lse - ly);
+      acc_ce += bad_label ? __builtin_nanf("") : w * (lse - ly);
       acc_w += w;
-      const float k = w * inv_w, inv_se = 1.f / se;
+      const float k = bad_label ? __builtin_nanf("") : w * inv_w, inv_se = 1.f / se;
 #pragma unroll
       for (int j = 0; j < MAXC; ++j)
         if (j < a.n_cls) drow[a.sr_dims + j] = k * (lg[j] * inv_se - (j == y ? 1.f : 0.f));

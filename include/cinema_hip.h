@@ -16,6 +16,10 @@
  *   - return value: 0 = ok, otherwise a hipError_t or a negative library code;
  *     cinema_last_error() returns a thread-local description of the last failure;
  *   - the caller (PyTorch) owns every buffer; the library allocates nothing.
+ *   - host state: a few per-device caches (CU count, kernel LDS attributes, the address of the no-alloc scratch), indexed
+ *     by the HIP device that is current at the call, so one process may drive several devices; calls on different streams
+ *     of one device may run concurrently unless an entry point says otherwise.  The debug trace selector
+ *     (cinema_debug_fused_trace) and the CINEMA_* environment switches are process-wide.
  *   - precision: 0 = fp32 (exact-f32 MFMA), 1 = bf16 (bf16 MFMA, fp32 accumulate).  The
  *     element type "T" of activation / packed-weight buffers follows it.
  *   - Npad = N rounded up to a multiple of 128.  Row buffers have Npad rows; rows >= N are

@@ -155,6 +155,24 @@ def test_g6_criterion_golden():
         crit(o, T(g[pre + "target"]).to(dev()), None)
 
 
+def test_out_of_range_label_is_not_silent():
+    """A segmentation label outside [0, n_cls) aborts the reference's CrossEntropyLoss; the K3 kernel marks the loss and
+    that sample's gradient row with NaN instead of clamping the label quietly."""
+    from cinema_amd.utils import Criterion
+    args = make_args([8, 1, 1, 1], 16, 1, [1], [2, 10], 0, "fp32", loss_metric="mse", class_weights=None, tf_weight=0.0)
+    crit = Criterion(args)
+    o = torch.randn(40, 12, device=dev(), requires_grad=True)
+    target = torch.cat((torch.rand(40, 2), torch.randint(1, 10, (40, 1)).float()), 1).to(dev())
+    tfs = torch.zeros(40, 6, device=dev(), requires_grad=True)
+    good = crit(o, target, tfs, seg_weight=1.0)
+    assert bool(torch.isfinite(good["total"]))
+    target[7, 2] = 10.0
+    bad = crit(o, target, tfs, seg_weight=1.0)
+    assert bool(torch.isnan(bad["seg"])) and bool(torch.isfinite(bad["sr"]))
+    bad["total"].backward()
+    assert bool(torch.isnan(o.grad[7, 2:]).all()) and bool(torch.isfinite(o.grad[8]).all())
+
+
 def _oracle_case(N, S, latent_dim, hidden, layers, mod, out_dim, cond, seed, precision, loss_metric="mse", tf_table=False):
     from oracle import cinema_oracle as O
     from cinema_amd.models.inr_decoder import INR_Decoder
