@@ -94,6 +94,9 @@ SIGNATURES = {
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_normed": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P, _P],
     "cinema_step_prepare": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P],
+    "cinema_conv_mod_work_bytes": [_I64, _I32, _I32, _I32, _I32, _I32, _I32],
+    "cinema_conv_mod_forward": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "cinema_conv_mod_backward": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_sine_layer_work_bytes": [_P, _I64],
     "cinema_sine_layer_forward": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
     "cinema_sine_layer_backward": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -103,7 +106,7 @@ SIGNATURES = {
     "cinema_infer_rescale": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_grid_coords": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
 }
-_RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64}
+_RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64, "cinema_conv_mod_work_bytes": C.c_int64}
 
 _lib = None
 

@@ -1504,3 +1504,212 @@ extern "C" int cinema_sine_layer_backward(const cinema_sine_layer_desc *d, const
   return d->precision == CINEMA_PREC_BF16 ? sine_layer_backward_impl<bf16_t>(d, p, W, N, work, dout, dx, dlatent, dW, db, dWl, dbl, s)
                                           : sine_layer_backward_impl<float>(d, p, W, N, work, dout, dx, dlatent, dW, db, dWl, dbl, s);
 }
+
+// ----------------------------------------------------------------------------------------
+// Modulator with cnn_kernel_size = k > 0 (models/inr_decoder.py:109-123): Conv3d(C, C, k, padding='same') over the
+// latent table (S, C, lx, ly, lz).  The table is tiny in space (G = lx*ly*lz nodes) and wide in channels, so the
+// convolution is three GEMMs over an im2col image, all through the split-K weight-gradient engine (k_dw_grouped):
+//   forward  outT[co][(s,n)]   = sum_{(tap,ci)} W2T[(tap,ci)][co] * colT[(tap,ci)][(s,n)]        colT = im2col(in, +)
+//   d weight dW2[co][(tap,ci)] = sum_{(s,n)}    doutR[(s,n)][co]  * col[(s,n)][(tap,ci)]         col  = im2col(in, +)
+//   d input  dinT[ci][(s,m)]   = sum_{(tap,co)} W3T[(tap,co)][ci] * dcolT[(tap,co)][(s,m)]       dcolT = im2col(dout, -)
+// with col element ((s,n), (tap,c)) = x[s][c][n +- offset(tap)] or 0 outside the grid.
+// ----------------------------------------------------------------------------------------
+namespace {
+struct ConvGeom { int S, C, lx, ly, lz, k, G, K3; long R, KK, KKp; };
+
+__device__ __forceinline__ int conv_neighbour(const ConvGeom &g, int n, int tap, int sign) {
+  const int p = g.k >> 1;
+  const int tz = tap % g.k, ty = (tap / g.k) % g.k, tx = tap / (g.k * g.k);
+  const int iz = n % g.lz, iy = (n / g.lz) % g.ly, ix = n / (g.lz * g.ly);
+  const int jx = ix + sign * (tx - p), jy = iy + sign * (ty - p), jz = iz + sign * (tz - p);
+  if (jx < 0 || jx >= g.lx || jy < 0 || jy >= g.ly || jz < 0 || jz >= g.lz) return -1;
+  return (jx * g.ly + jy) * g.lz + jz;
+}
+
+// TRANSPOSED = false: col [R][KKp] (channel fastest); true: colT [KKp][R] ((s, n) fastest).  Pads are written as zeros.
+template <typename T, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_conv_im2col(const float *x, ConvGeom g, int sign, T *dst) {
+  const long total = g.R * g.KKp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = TRANSPOSED ? e % g.R : e / g.KKp, kc = TRANSPOSED ? e / g.R : e % g.KKp;
+    float v = 0.f;
+    if (row < (long)g.S * g.G && kc < g.KK) {
+      const int s = (int)(row / g.G), n = (int)(row % g.G), tap = (int)(kc / g.C), c = (int)(kc % g.C);
+      const int nb = conv_neighbour(g, n, tap, sign);
+      if (nb >= 0) v = x[((long)s * g.C + c) * g.G + nb];
+    }
+    dst[e] = (T)v;
+  }
+}
+
+// W [co][ci][K3] -> dst [(tap, a)][b] with (a, b) = (ci, co) (forward operand) or (co, ci) (d input operand); pads zero
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_pack_w(const float *W, ConvGeom g, int for_dinput, T *dst) {
+  const long total = g.KKp * g.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long kc = e / g.C;
+    const int b = (int)(e % g.C);
+    float v = 0.f;
+    if (kc < g.KK) {
+      const int tap = (int)(kc / g.C), a = (int)(kc % g.C);
+      const int co = for_dinput ? a : b, ci = for_dinput ? b : a;
+      v = W[((long)co * g.C + ci) * g.K3 + tap];
+    }
+    dst[e] = (T)v;
+  }
+}
+
+// x [S][C][G] fp32 -> rows [R][C] T ((s, n) rows, channel fastest); pad rows zero
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_rows(const float *x, ConvGeom g, T *dst) {
+  const long total = g.R * g.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / g.C;
+    const int c = (int)(e % g.C);
+    float v = 0.f;
+    if (row < (long)g.S * g.G) v = x[((row / g.G) * g.C + c) * g.G + row % g.G];
+    dst[e] = (T)v;
+  }
+}
+
+// yT [C][R] fp32 (+ bias[c]) -> y [S][C][G]
+__global__ __launch_bounds__(256) void k_conv_untranspose(const float *yT, const float *bias, ConvGeom g, float *y) {
+  const long total = (long)g.S * g.C * g.G;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e % g.G), c = (int)((e / g.G) % g.C);
+    const long s = e / ((long)g.G * g.C);
+    y[e] = yT[(long)c * g.R + s * g.G + n] + (bias ? bias[c] : 0.f);
+  }
+}
+
+// dW2 [C][KKp] ((tap, ci) columns) -> dW [co][ci][K3]; db[co] = sum of dout over subjects and nodes (one block per co)
+__global__ __launch_bounds__(256) void k_conv_wgrad_finish(const float *dW2, const float *dout, ConvGeom g, float *dW, float *db) {
+  const int co = blockIdx.x;
+  for (int e = threadIdx.x; e < g.C * g.K3; e += 256) {
+    const int ci = e / g.K3, tap = e % g.K3;
+    dW[((long)co * g.C + ci) * g.K3 + tap] = dW2[(long)co * g.KKp + (long)tap * g.C + ci];
+  }
+  float acc = 0.f;
+  for (long e = threadIdx.x; e < (long)g.S * g.G; e += 256) acc += dout[((e / g.G) * g.C + co) * g.G + e % g.G];
+  __shared__ float red[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) db[co] = red[0] + red[1] + red[2] + red[3];
+}
+
+bool conv_geom(int64_t S, int C, int lx, int ly, int lz, int k, ConvGeom &g) {
+  if (S < 1 || C < 8 || C % 8 || lx < 1 || ly < 1 || lz < 1 || k < 1 || !(k & 1) || (long)lx * ly * lz > 4096) return false;
+  g.S = (int)S; g.C = C; g.lx = lx; g.ly = ly; g.lz = lz; g.k = k; g.G = lx * ly * lz; g.K3 = k * k * k;
+  g.R = ((long)S * g.G + 127) / 128 * 128;
+  g.KK = (long)g.K3 * C;
+  g.KKp = (g.KK + 127) / 128 * 128;
+  return true;
+}
+
+struct ConvWork { size_t colT, col, wT, rows, outT, dW2, bytes; };
+ConvWork conv_work(const ConvGeom &g, int precision) {
+  const size_t e = precision == CINEMA_PREC_BF16 ? 2 : 4;
+  ConvWork w;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 255) / 256 * 256; return at; };
+  w.colT = take((size_t)g.KKp * g.R * e);
+  w.col = take((size_t)g.R * g.KKp * e);
+  w.wT = take((size_t)g.KKp * g.C * e);
+  w.rows = take((size_t)g.R * g.C * e);
+  w.outT = take((size_t)g.C * g.R * 4);
+  w.dW2 = take((size_t)g.C * g.KKp * 4);
+  w.bytes = o;
+  return w;
+}
+
+// out[M x K] (zeroed here) = sum over `nrows` rows of P[n][0..M) * Q[n][0..K): one k_dw_grouped problem, split over rows
+template <typename T>
+int conv_gemm(const void *P, int ldp, const void *Q, int ldq, float *out, int ldo, int M, int K, long nrows, hipStream_t s) {
+  CINEMA_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * ldo * sizeof(float), s));
+  DwArgs w = {};
+  DwProb pr = {P, Q, out, ldp, ldq, ldo, M, K, (K + 127) / 128};
+  w.p[0] = pr;
+  const int tiles = ((M + 127) / 128) * pr.tk;
+  w.tile_start[0] = 0; w.tile_start[1] = tiles; w.nprob = 1; w.Npad = (int)nrows;
+  const int ntile = (int)(nrows / Engine<T>::BN);
+  w.splitk = std::min(std::max(1, 1024 / std::max(tiles, 1)), std::max(1, ntile / 4));
+  constexpr int smem = Engine<T>::TN_SMEM;
+  CINEMA_SMEM_ATTR(k_dw_grouped<T>, smem);
+  hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * w.splitk), dim3(WG_THREADS), smem, s, w);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+inline unsigned conv_grid(long total) { return (unsigned)std::min<long>((total + 255) / 256, 8192); }
+
+template <typename T>
+int conv_forward_impl(const ConvGeom &g, const ConvWork &w, const float *in, const float *W, const float *b, void *work,
+                      float *out, hipStream_t s) {
+  char *wk = (char *)work;
+  T *colT = (T *)(wk + w.colT), *wT = (T *)(wk + w.wT);
+  float *outT = (float *)(wk + w.outT);
+  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, in, g, 1, colT);
+  hipLaunchKernelGGL((k_conv_pack_w<T>), dim3(conv_grid(g.KKp * g.C)), dim3(256), 0, s, W, g, 0, wT);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s)) return rc;
+  hipLaunchKernelGGL(k_conv_untranspose, dim3(conv_grid((long)g.S * g.C * g.G)), dim3(256), 0, s, outT, b, g, out);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int conv_backward_impl(const ConvGeom &g, const ConvWork &w, const float *in, const float *W, const float *dout, void *work,
+                       float *din, float *dW, float *db, hipStream_t s) {
+  char *wk = (char *)work;
+  T *colT = (T *)(wk + w.colT), *col = (T *)(wk + w.col), *wT = (T *)(wk + w.wT), *rows = (T *)(wk + w.rows);
+  float *outT = (float *)(wk + w.outT), *dW2 = (float *)(wk + w.dW2);
+  // d weight (+ d bias)
+  hipLaunchKernelGGL((k_conv_im2col<T, false>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, in, g, 1, col);
+  hipLaunchKernelGGL((k_conv_rows<T>), dim3(conv_grid(g.R * g.C)), dim3(256), 0, s, dout, g, rows);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  if (int rc = conv_gemm<T>(rows, g.C, col, (int)g.KKp, dW2, (int)g.KKp, g.C, (int)g.KK, g.R, s)) return rc;
+  hipLaunchKernelGGL(k_conv_wgrad_finish, dim3(g.C), dim3(256), 0, s, dW2, dout, g, dW, db);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  // d input: the same GEMM shape as the forward on the mirrored image of dout
+  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, dout, g, -1, colT);
+  hipLaunchKernelGGL((k_conv_pack_w<T>), dim3(conv_grid(g.KKp * g.C)), dim3(256), 0, s, W, g, 1, wT);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s)) return rc;
+  hipLaunchKernelGGL(k_conv_untranspose, dim3(conv_grid((long)g.S * g.C * g.G)), dim3(256), 0, s, outT, (const float *)nullptr, g, din);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t cinema_conv_mod_work_bytes(int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t k, int32_t precision) {
+  ConvGeom g;
+  if (!conv_geom(S, C, lx, ly, lz, k, g) || (precision != CINEMA_PREC_F32 && precision != CINEMA_PREC_BF16)) {
+    cinema_set_error("cinema_conv_mod_work_bytes: need S >= 1, C a multiple of 8, an odd kernel size, a valid precision");
+    return -1;
+  }
+  return (int64_t)conv_work(g, precision).bytes;
+}
+
+extern "C" int cinema_conv_mod_forward(const float *in, const float *W, const float *b, int64_t S, int32_t C, int32_t lx,
+                                       int32_t ly, int32_t lz, int32_t k, int32_t precision, void *work, float *out,
+                                       void *stream) {
+  ConvGeom g;
+  CINEMA_REQUIRE(conv_geom(S, C, lx, ly, lz, k, g), "cinema_conv_mod_forward: bad shape (see cinema_conv_mod_work_bytes)");
+  CINEMA_REQUIRE(in && W && b && work && out, "cinema_conv_mod_forward: null argument");
+  const ConvWork w = conv_work(g, precision);
+  return precision == CINEMA_PREC_BF16 ? conv_forward_impl<bf16_t>(g, w, in, W, b, work, out, (hipStream_t)stream)
+                                       : conv_forward_impl<float>(g, w, in, W, b, work, out, (hipStream_t)stream);
+}
+
+extern "C" int cinema_conv_mod_backward(const float *in, const float *W, const float *dout, int64_t S, int32_t C, int32_t lx,
+                                        int32_t ly, int32_t lz, int32_t k, int32_t precision, void *work, float *din,
+                                        float *dW, float *db, void *stream) {
+  ConvGeom g;
+  CINEMA_REQUIRE(conv_geom(S, C, lx, ly, lz, k, g), "cinema_conv_mod_backward: bad shape (see cinema_conv_mod_work_bytes)");
+  CINEMA_REQUIRE(in && W && dout && work && din && dW && db, "cinema_conv_mod_backward: null argument");
+  const ConvWork w = conv_work(g, precision);
+  return precision == CINEMA_PREC_BF16 ? conv_backward_impl<bf16_t>(g, w, in, W, dout, work, din, dW, db, (hipStream_t)stream)
+                                       : conv_backward_impl<float>(g, w, in, W, dout, work, din, dW, db, (hipStream_t)stream);
+}

@@ -217,3 +217,40 @@ class SineLayerFunction(torch.autograd.Function):
                                                   _lib.ptr(dlat), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dwl), _lib.ptr(dbl), stream),
                    "cinema_sine_layer_backward")
         return None, dx, dlat, dw, db, dwl, dbl
+
+
+class ConvModFunction(torch.autograd.Function):
+    """Modulator's Conv3d(C, C, k, padding='same') over the latent table (models/inr_decoder.py:109-123) through
+    cinema_conv_mod_forward / _backward (include/cinema_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, table, weight, bias, precision: int):
+        lib = _lib.load()
+        S, Cc, lx, ly, lz = table.shape
+        k = weight.shape[2]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        x, w, b = f32(table), f32(weight), f32(bias)
+        nbytes = lib.cinema_conv_mod_work_bytes(S, Cc, lx, ly, lz, k, precision)
+        if nbytes < 0:
+            _lib.check(-1, "cinema_conv_mod_work_bytes")
+        work = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+        out = torch.empty_like(x)
+        stream = C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)
+        _lib.check(lib.cinema_conv_mod_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), S, Cc, lx, ly, lz, k, precision, _lib.ptr(work),
+                                               _lib.ptr(out), stream), "cinema_conv_mod_forward")
+        ctx.save_for_backward(x, w)
+        ctx.work, ctx.geom = work, (S, Cc, lx, ly, lz, k, precision)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        S, Cc, lx, ly, lz, k, precision = ctx.geom
+        g = gout.detach().to(torch.float32).contiguous()
+        din, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty(Cc, dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.cinema_conv_mod_backward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(g), S, Cc, lx, ly, lz, k, precision,
+                                                _lib.ptr(ctx.work), _lib.ptr(din), _lib.ptr(dw), _lib.ptr(db), stream),
+                   "cinema_conv_mod_backward")
+        return din, dw, db, None

@@ -23,18 +23,34 @@ from .siren import Siren
 
 class Modulator(nn.Module):
     """Reference: models/inr_decoder.py:109-123.  Identity for kernel_size == 0 (the default,
-    config_atlas.yaml:74), else Conv3d(C, C, k, padding='same') over the latent table (run by
-    MIOpen through torch; it acts on the (S,C,lx,ly,lz) table, not on the sample stream)."""
+    config_atlas.yaml:74), else Conv3d(C, C, k, padding='same') over the latent table (S, C, lx, ly, lz).  `conv` is the
+    reference's nn.Conv3d as the parameter container (state_dict keys conv.weight / conv.bias, torch's initialisation);
+    its arithmetic runs in the HIP library (cinema_conv_mod_forward / _backward: im2col + split-K MFMA GEMMs, `precision`
+    'bf16' | 'fp32' | None = engine default)."""
 
-    def __init__(self, latent_dims, kernel_size=3):
+    def __init__(self, latent_dims, kernel_size=3, precision=None):
         super().__init__()
+        self.kernel_size = kernel_size
+        self.precision = precision
         if kernel_size > 0:
+            if kernel_size % 2 == 0:
+                raise NotImplementedError("cinema_amd Modulator: even cnn_kernel_size (asymmetric 'same' padding) is not built")
             self.conv = nn.Conv3d(latent_dims[0], latent_dims[0], kernel_size, padding="same")
         else:
             self.conv = nn.Identity()
 
     def forward(self, latent_vecs):
-        return self.conv(latent_vecs)
+        if self.kernel_size <= 0:
+            return latent_vecs
+        if not latent_vecs.is_cuda:
+            raise RuntimeError("cinema_amd Modulator runs HIP kernels: the latent table must live on the GPU")
+        from ..functions import ConvModFunction
+        prec = self.precision
+        if isinstance(prec, str):
+            prec = _lib.PREC_BF16 if prec.lower() in ("bf16", "bfloat16") else _lib.PREC_F32
+        if prec is None:
+            prec = E.default_precision()
+        return ConvModFunction.apply(latent_vecs, self.conv.weight, self.conv.bias, prec)
 
 
 class LatentRegressor(nn.Module):
@@ -58,12 +74,12 @@ class INR_Decoder(nn.Module):
         self.sr_dims = sum(a["out_dim"][:-1])
         self.out_dim = sum(a["out_dim"])
         self.mod_dim = a["hidden_size"] * len(a["modulated_layers"]) * 2
-        self.modulator = Modulator(a["latent_dim"], kernel_size=a["cnn_kernel_size"])
         precision = a.get("precision", None)
         if isinstance(precision, str):
             precision = _lib.PREC_BF16 if precision.lower() in ("bf16", "bfloat16") else _lib.PREC_F32
         if precision is None:
             precision = E.default_precision(args.get("amp", None))
+        self.modulator = Modulator(a["latent_dim"], kernel_size=a["cnn_kernel_size"], precision=precision)
         self.sr_net = Siren(a["in_dim"], a["latent_dim"][0] + a["cond_dims"], self.out_dim, a["hidden_size"],
                             a["num_hidden_layers"], f_om=a["omega"][0], h_om=a["omega"][1], outermost_linear=True,
                             modulated_layers=a["modulated_layers"], precision=precision)

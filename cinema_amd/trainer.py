@@ -93,6 +93,9 @@ class HotPathTrainer:
         """keep_grads=True leaves the step's gradients in lat_grad / tf_grad / eng.flat_grad for inspection; by default the
         optimiser launch zeroes them as it consumes them (the next step then needs no zero_grad fill)."""
         import torch.distributed as dist
+        if args["inr_decoder"].get("cnn_kernel_size", 0) > 0:
+            raise NotImplementedError("HotPathTrainer steps the Identity modulator (cnn_kernel_size 0, the reference's default); "
+                                      "with a Conv3d modulator train through the module API (INR_Decoder + Criterion + HipAdamW)")
         self.args, self.store, self.device, self.split = args, store, torch.device(device), split
         self.pg = process_group
         self.keep_grads = bool(keep_grads)

@@ -153,6 +153,19 @@ int cinema_sine_layer_forward(const cinema_sine_layer_desc *d, const float *x, c
 int cinema_sine_layer_backward(const cinema_sine_layer_desc *d, const float *W, int64_t N, void *work, const float *dout,
                                float *dx, float *dlatent, float *dW, float *db, float *dWl, float *dbl, void *stream);
 
+/* Modulator with cnn_kernel_size = k > 0 -- Conv3d(C, C, k, padding='same') over the latent table, models/inr_decoder.py:
+ * 109-123 (the default k = 0 is the identity and needs no call).  in / out / dout / din [S x C x lx x ly x lz] fp32,
+ * W [C x C x k x k x k], b [C] (torch layouts).  k odd, C a multiple of 8.  The convolution runs as GEMMs over an im2col
+ * image of the table (three for the backward), in the arithmetic `precision` selects.  work: cinema_conv_mod_work_bytes
+ * bytes of device memory; the two calls are independent (the backward rebuilds what it needs from `in`).
+ * The backward overwrites din, dW, db (what autograd leaves for the table, conv.weight and conv.bias). */
+int64_t cinema_conv_mod_work_bytes(int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t k, int32_t precision);
+int cinema_conv_mod_forward(const float *in, const float *W, const float *b, int64_t S, int32_t C, int32_t lx, int32_t ly,
+                            int32_t lz, int32_t k, int32_t precision, void *work, float *out, void *stream);
+int cinema_conv_mod_backward(const float *in, const float *W, const float *dout, int64_t S, int32_t C, int32_t lx, int32_t ly,
+                             int32_t lz, int32_t k, int32_t precision, void *work, float *din, float *dW, float *db,
+                             void *stream);
+
 /* Backward of the above (what autograd does for siren.py:26-36,59-61).
  * dout [Npad x out_dim] fp32 (rows >= N must be zero), gbuf [n_gbuf x Npad x HP] T scratch followed (at the next
  * multiple of 256 bytes) by gb_extra_bytes more bytes,

@@ -473,3 +473,65 @@ def test_inference_forward_keeps_nothing_and_matches():
     rc = e32.lib.cinema_siren_forward(C.byref(e32.desc), ptr(e32.flat), ptr(e32.packed), ptr(e32.ws.coords_t), ptr(e32.ws.lat),
                                       n, (n + 127) // 128 * 128, None, ptr(e32.ws.out), e32.stream())
     assert rc != 0 and b"saved" in e32.lib.cinema_last_error()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("S,C,grid,k", [(5, 48, (3, 3, 3), 3), (64, 256, (3, 3, 3), 3), (3, 16, (2, 3, 4), 5), (2, 32, (1, 1, 1), 3)])
+def test_conv_modulator_matches_torch_conv3d(S, C, grid, k, precision):
+    """Modulator with cnn_kernel_size > 0 (models/inr_decoder.py:109-123): forward and all three
+    gradients of Conv3d(C, C, k, padding='same') over the latent table against torch's conv3d in float64 on the host
+    (the reference's own op), incl. the bench's table size, a non-cubic grid with a kernel wider than the grid, 1^3."""
+    import torch.nn.functional as F
+    from cinema_amd.models.inr_decoder import Modulator
+    torch.manual_seed(S * 1000 + C)
+    mod = Modulator([C, *grid], kernel_size=k, precision=precision).to(dev())
+    x = (torch.randn(S, C, *grid) * 0.1).to(dev()).requires_grad_(True)
+    gy = torch.randn(S, C, *grid).to(dev())
+    y = mod(x)
+    (y * gy).sum().backward()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    wr, br = (p.detach().cpu().double().requires_grad_(True) for p in (mod.conv.weight, mod.conv.bias))
+    yr = F.conv3d(xr, wr, br, padding="same")
+    (yr * gy.cpu().double()).sum().backward()
+    errs = both_errs("y", y.detach().cpu().numpy(), yr.detach().numpy())
+    errs.update(both_errs("gx", x.grad.cpu().numpy(), xr.grad.numpy()))
+    errs.update(both_errs("gw", mod.conv.weight.grad.cpu().numpy(), wr.grad.numpy()))
+    errs.update(both_errs("gb", mod.conv.bias.grad.cpu().numpy(), br.grad.numpy()))
+    bad = failing(errs, TOL[precision], L2_TOL[precision])
+    assert not bad, f"{bad}\nall: {errs}"
+
+
+def test_decoder_with_conv_modulator_matches_oracle():
+    """INR_Decoder with cnn_kernel_size = 3 end to end (conv over the table, then the usual path) against the CPU oracle
+    fed with torch's conv3d of the table; the conv parameters get gradients through the HIP backward."""
+    import torch.nn.functional as F
+    from oracle import cinema_oracle as O
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import Criterion
+    args = make_args([32, 3, 3, 3], 128, 3, [1, 3], [2, 6], 0, "fp32", loss_metric="mse", class_weights=None, tf_weight=0.0)
+    args["inr_decoder"]["cnn_kernel_size"] = 3
+    torch.manual_seed(9)
+    dec, crit = INR_Decoder(args, "cuda:0").to(dev()), Criterion(args)
+    gen = torch.Generator().manual_seed(10)
+    S, N = 6, 900
+    lat = torch.randn(S, 32, 3, 3, 3, generator=gen) * 0.1
+    tft = (torch.rand(S, 6, generator=gen) - 0.5) * 0.1
+    coords = torch.rand(N, 3, generator=gen) * 1.9 - 0.95
+    idx = torch.randint(0, S, (N,), generator=gen, dtype=torch.int32)
+    target = torch.cat((torch.rand(N, 2, generator=gen), torch.randint(1, 6, (N, 1), generator=gen).float()), 1)
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    params = {k[len("sr_net."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("sr_net.")}
+    cw, cb = sd["modulator.conv.weight"].clone().requires_grad_(True), sd["modulator.conv.bias"].clone().requires_grad_(True)
+    lat_o, tft_o = lat.clone().requires_grad_(True), tft.clone().requires_grad_(True)
+    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse", class_weights=None, tf_weight=0.0)
+    loss_o, out_o = O.training_step(params, F.conv3d(lat_o, cw, cb, padding="same"), tft_o, coords, target, idx, None, cfg)
+    lat_g, tft_g = lat.to(dev()).requires_grad_(True), tft.to(dev()).requires_grad_(True)
+    out = dec(coords.to(dev()), lat_g, torch.zeros(N, 0, device=dev()), tft_g, idcs_df=idx.to(dev()), tf_table=True)
+    crit(out, target.to(dev()), tft_g[idx.to(dev()).long()], seg_weight=1.0)["total"].backward()
+    errs = both_errs("out", out.detach().cpu().numpy(), out_o.detach().numpy())
+    errs.update(both_errs("glat", lat_g.grad.cpu().numpy(), lat_o.grad.numpy()))
+    errs.update(both_errs("g_conv_w", dec.modulator.conv.weight.grad.cpu().numpy(), cw.grad.numpy()))
+    errs.update(both_errs("g_conv_b", dec.modulator.conv.bias.grad.cpu().numpy(), cb.grad.numpy()))
+    errs.update(both_errs("g_final_w", dec.sr_net.final_linear.weight.grad.cpu().numpy(), params["final_linear.weight"].grad.numpy()))
+    bad = failing(errs, TOL["fp32"], L2_TOL["fp32"])
+    assert not bad, f"{bad}\nall: {errs}"
