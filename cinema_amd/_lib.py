@@ -103,6 +103,7 @@ SIGNATURES = {
     "cinema_infer_minmax": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_infer_finish": [_P, _I64, _I32, _I32, _P, _P, _P],
     "cinema_infer_chunk": [_P, _I64, _I32, _I32, _P, _P, _P],
+    "cinema_cc_label": [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "cinema_infer_rescale": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_grid_coords": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
 }

@@ -267,6 +267,39 @@ __global__ __launch_bounds__(256) void k_grid_coords(const float *ax, const floa
   }
 }
 
+// ---- connected components of a 3-d mask (6-connectivity), labels = 1 + smallest linear index of the component ----
+__global__ __launch_bounds__(256) void k_cc_init(const uint8_t *mask, long V, int32_t *lab) {
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) lab[v] = mask[v] ? (int32_t)(v + 1) : 0;
+}
+
+// one sweep: take the smallest label among a voxel and its 6 neighbours, then follow the label chain (a label names a
+// voxel of the same component whose own label is smaller or equal) a few hops.  Labels only ever decrease and only to
+// labels of the same component, so in-place races cost sweeps, never correctness; *changed counts the updates.
+__global__ __launch_bounds__(256) void k_cc_sweep(int32_t *lab, int X, int Y, int Z, int32_t *changed) {
+  const long V = (long)X * Y * Z;
+  int any = 0;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const int32_t own = lab[v];
+    if (own == 0) continue;
+    const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((long)Z * Y));
+    int32_t m = own;
+    auto look = [&](long u) { const int32_t l = lab[u]; if (l != 0 && l < m) m = l; };
+    if (z > 0) look(v - 1);
+    if (z + 1 < Z) look(v + 1);
+    if (y > 0) look(v - Z);
+    if (y + 1 < Y) look(v + Z);
+    if (x > 0) look(v - (long)Z * Y);
+    if (x + 1 < X) look(v + (long)Z * Y);
+#pragma unroll
+    for (int hop = 0; hop < 4; ++hop) {
+      const int32_t up = lab[m - 1];
+      if (up != 0 && up < m) m = up;
+    }
+    if (m < own) { atomicMin(lab + v, m); atomicMin(lab + (own - 1), m); any = 1; }
+  }
+  if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(changed, 1);
+}
+
 }  // namespace
 
 static int sample_loss_impl(bool prepared, const float *out, const float *target, const int64_t *voxel, const int32_t *subj,
@@ -382,6 +415,20 @@ extern "C" int cinema_grid_coords(const float *ax, const float *ay, const float 
   const unsigned grid = (unsigned)std::min<long>((count + 255) / 256, 4096);
   hipLaunchKernelGGL(k_grid_coords, dim3(grid), dim3(256), 0, (hipStream_t)stream, ax, ay, az, (long)ny, (long)nz, (long)start,
                      (long)count, coords);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cinema_cc_label(const uint8_t *mask, int32_t X, int32_t Y, int32_t Z, int32_t *labels, int32_t *changed,
+                               int32_t sweeps, int32_t init, void *stream) {
+  CINEMA_REQUIRE(mask && labels && changed && X >= 1 && Y >= 1 && Z >= 1 && sweeps >= 0 && (long)X * Y * Z < (1L << 31) - 1,
+                 "cinema_cc_label: bad argument");
+  const long V = (long)X * Y * Z;
+  const unsigned grid = (unsigned)std::min<long>((V + 255) / 256, 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (init) hipLaunchKernelGGL(k_cc_init, dim3(grid), dim3(256), 0, s, mask, V, labels);
+  CINEMA_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int32_t), s));
+  for (int k = 0; k < sweeps; ++k) hipLaunchKernelGGL(k_cc_sweep, dim3(grid), dim3(256), 0, s, labels, X, Y, Z, changed);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

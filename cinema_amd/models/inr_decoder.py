@@ -184,10 +184,8 @@ class INR_Decoder(nn.Module):
                        "cinema_infer_rescale")
         modalities_rec = vol.reshape(list(img_shape) + [-1])
         if self.args.get("mask_reconstruction", False):
-            # models/inr_decoder.py:87-107 (largest central component + dilation on the host through scipy) is SURVEY.md
-            # section 8(f)-4, not built: refuse rather than return an unmasked volume under that flag
-            raise NotImplementedError("INR_Decoder.inference: post-hoc mask_reconstruction is not part of the hot path "
-                                      "(SURVEY.md section 8(f)-4); run with mask_reconstruction: False")
+            from ..postmask import mask_reconstruction       # models/inr_decoder.py:59-60, 87-107, on the GPU
+            return mask_reconstruction(modalities_rec, sr, self.args["dataset"]["label_names"])
         return modalities_rec
 
     # ------------------------------------------------------------------------------------

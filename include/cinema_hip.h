@@ -399,6 +399,14 @@ int cinema_infer_chunk(const float *out, int64_t G, int32_t out_dim, int32_t sr_
                        void *stream);
 int cinema_infer_rescale(float *vol, int64_t G, int32_t out_dim, int32_t sr_dims, const float *minmax, void *stream);
 
+/* Connected components of a 3-d mask [X x Y x Z] uint8 with 6-connectivity (what scipy.ndimage.label computes for the
+ * post-hoc masking of a reconstruction, models/inr_decoder.py:92-104): labels[v] = 0 outside the mask, else 1 + the
+ * smallest linear index of v's component (so labels order like scipy's raster-scan numbering).  init != 0 starts from
+ * the mask; every call runs `sweeps` propagation sweeps and leaves in *changed (device int32) how many waves still
+ * updated a label in them: call again with init = 0 until it reads 0. */
+int cinema_cc_label(const uint8_t *mask, int32_t X, int32_t Y, int32_t Z, int32_t *labels, int32_t *changed, int32_t sweeps,
+                    int32_t init, void *stream);
+
 /* Coordinates [count x 3] of the run [start, start + count) of the dense evaluation grid, x-major flattening of the three
  * axis vectors (utils.py:235-250 builds the whole meshgrid, 357 MB at 310^3; the chunked evaluation makes each run). */
 int cinema_grid_coords(const float *ax, const float *ay, const float *az, int64_t nx, int64_t ny, int64_t nz, int64_t start,

@@ -85,3 +85,75 @@ def test_generate_atlas_writes_the_reference_file_set(tmp_path):
             assert img.shape == (12, 12, 12, 2) and img.get_data_dtype() == np.float32
             assert np.array_equal(img.get_fdata(), vol[..., i, c, :].numpy().astype(np.float64), equal_nan=True)
             assert np.array_equal(np.diag(img.affine), [5.0, 5.0, 5.0, 1.0])
+
+
+def test_posthoc_mask_matches_scipy():
+    """mask_reconstruction after inference (reference models/inr_decoder.py:87-107: scipy label + centre-patch majority +
+    Gaussian widening on the host) on the GPU: cinema_cc_label + device ops, against scipy as the checker.  Several
+    components (one through the centre, a larger one off-centre, a snake that needs many propagation sweeps), then a
+    volume whose central patch is mostly background (everything is masked away, as in the reference)."""
+    import numpy as np
+    import scipy.ndimage as ndi
+    from cinema_amd.postmask import central_component_mask, component_labels, mask_reconstruction
+    names = ["none", "a", "b", "BG", "c"]
+    rng = np.random.default_rng(4)
+
+    def reference_mask(seg):
+        mask = (seg > 0) & (seg != 3)
+        shp = np.array(mask.shape)
+        ps, cp = ((shp * 0.1) // 2).astype(int), shp // 2
+        lab, _ = ndi.label(mask)
+        centre = lab[cp[0] - ps[0]:cp[0] + ps[0], cp[1] - ps[1]:cp[1] + ps[1], cp[2] - ps[2]:cp[2] + ps[2]].flatten()
+        mask = mask * (lab == np.argmax(np.bincount(centre)))
+        return (ndi.gaussian_filter(mask.astype(np.float32), sigma=1.0) > 0.001).astype(np.float32), lab
+
+    seg = np.zeros((40, 44, 48), dtype=np.int64)
+    seg[14:27, 16:29, 18:31] = rng.integers(1, 3, size=(13, 13, 13))          # through the centre
+    seg[14:27, 16:29, 18:31][rng.random((13, 13, 13)) < 0.2] = 0               # with holes
+    seg[18:23, 20:25, 22:27] = 4                                               # solid core in the central patch
+    seg[1:12, 1:40, 1:44] = 2                                                  # larger, off-centre
+    seg[30:38, 2:5, 2:46] = 1                                                  # snake: long thin component
+    seg[30:33, 2:42, 43:46] = 1
+    seg[28:30, 30:40, 10:20] = 3                                               # BG label: not foreground
+    want, lab_ref = reference_mask(seg)
+    seg_t = torch.from_numpy(seg).to(DEV)
+    lab = component_labels((seg_t > 0) & (seg_t != 3)).cpu().numpy()
+    # same partition into components, numbered in the same order
+    assert np.array_equal(lab > 0, lab_ref > 0)
+    pairs = np.unique(np.stack((lab[lab > 0], lab_ref[lab_ref > 0])), axis=1)
+    assert pairs.shape[1] == lab_ref.max() and np.all(np.diff(pairs[0]) > 0) and np.all(np.diff(pairs[1]) > 0)
+    got = central_component_mask(seg_t.float(), names).cpu().numpy()
+    assert np.array_equal(got, want) and 0 < want.sum() < want.size
+    recs = torch.rand(40, 44, 48, 2 + 1 + 5, device=DEV)
+    recs[..., 2] = seg_t.float()
+    out = mask_reconstruction(recs, 2, names)
+    assert torch.equal(out, recs * torch.from_numpy(want).to(DEV).unsqueeze(-1))
+    # centre patch mostly background -> label 0 wins -> nothing is kept
+    seg2 = np.zeros((40, 44, 48), dtype=np.int64)
+    seg2[2:10, 2:10, 2:10] = 1
+    seg2[20, 22, 24] = 2
+    want2, _ = reference_mask(seg2)
+    assert want2.sum() == 0
+    assert float(central_component_mask(torch.from_numpy(seg2).to(DEV).float(), names).sum()) == 0.0
+    with pytest.raises(ValueError):
+        central_component_mask(torch.ones(12, 12, 12, device=DEV), names)
+
+
+def test_inference_with_mask_reconstruction_flag():
+    """args['mask_reconstruction'] = True: INR_Decoder.inference returns the masked volume (inr_decoder.py:59-60)."""
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.postmask import mask_reconstruction
+    from cinema_amd.utils import generate_world_grid
+    args = atlas_args("fp32")
+    args["atlas_gen"]["spacing"] = [2.5, 2.5, 2.5]                 # 24^3: the central patch is 2 voxels wide
+    args["dataset"]["label_names"] = ["none", "a", "b", "c", "BG"]
+    torch.manual_seed(3)
+    dec = INR_Decoder(args, DEV).to(DEV)
+    grid, shape, _ = generate_world_grid(args, device=DEV, lazy=True)
+    lat, cond = torch.randn(1, 16, 3, 3, 3, device=DEV) * 0.3, torch.tensor([0.01], device=DEV)
+    plain = dec.inference(grid, lat, cond, shape)
+    dec.args["mask_reconstruction"] = True
+    masked = dec.inference(grid, lat, cond, shape)
+    want = mask_reconstruction(plain, 2, args["dataset"]["label_names"])
+    assert masked.shape == plain.shape
+    assert torch.equal(torch.nan_to_num(masked), torch.nan_to_num(want))
