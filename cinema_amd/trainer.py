@@ -93,9 +93,6 @@ class HotPathTrainer:
         """keep_grads=True leaves the step's gradients in lat_grad / tf_grad / eng.flat_grad for inspection; by default the
         optimiser launch zeroes them as it consumes them (the next step then needs no zero_grad fill)."""
         import torch.distributed as dist
-        if args["inr_decoder"].get("cnn_kernel_size", 0) > 0:
-            raise NotImplementedError("HotPathTrainer steps the Identity modulator (cnn_kernel_size 0, the reference's default); "
-                                      "with a Conv3d modulator train through the module API (INR_Decoder + Criterion + HipAdamW)")
         self.args, self.store, self.device, self.split = args, store, torch.device(device), split
         self.pg = process_group
         self.keep_grads = bool(keep_grads)
@@ -118,6 +115,24 @@ class HotPathTrainer:
         self.tf_grad = torch.zeros_like(self.tfs)
         self.flat_param = nn.Parameter(self.eng.flat)
         self.flat_param.grad = self.eng.flat_grad
+        # Conv3d modulator (cnn_kernel_size > 0, models/inr_decoder.py:109-123): K1 reads conv(latents) instead of the
+        # latents; its parameters train in the MLP's group (they are part of inr_decoder.parameters(), build_atlas.py:
+        # 432-453) and their gradients are all-reduced like the flat one
+        self.conv = self.decoder.modulator.conv if a.get("cnn_kernel_size", 0) > 0 else None
+        self.conv_params = []
+        if self.conv is not None:
+            lib = _lib.load()
+            k = a["cnn_kernel_size"]
+            nbytes = lib.cinema_conv_mod_work_bytes(S, a["latent_dim"][0], *a["latent_dim"][1:], k, self.eng.desc.precision)
+            if nbytes < 0:
+                _lib.check(-1, "cinema_conv_mod_work_bytes")
+            self.conv_work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.table = torch.empty_like(self.latents.data)
+            self.table_grad = torch.zeros_like(self.latents.data)
+            for prm in (self.conv.weight, self.conv.bias):
+                par.broadcast_(prm.data, 0, process_group)
+                prm.grad = torch.zeros_like(prm.data)
+                self.conv_params.append(prm)
         self.train_mlp = split == "train"
         self.seg_weight = o["seg_weight"] if split == "train" else 0.0      # build_atlas.py:63
         cw = args["dataset"]["class_weights"]
@@ -130,7 +145,7 @@ class HotPathTrainer:
             groups.append({"params": [self.tfs], "lr": o["lr_tf"], "weight_decay": o["tf_weight_decay"]})
         if self.cond_param is not None:
             groups.append({"params": [self.cond_param], "lr": o["lr_latent"], "weight_decay": o["latent_weight_decay"]})
-        mlp_group = {"params": [self.flat_param], "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}
+        mlp_group = {"params": [self.flat_param] + self.conv_params, "lr": o["lr_inr"], "weight_decay": o["inr_weight_decay"]}
         if self.train_mlp and self.world == 1:
             # one process: nothing to wait for between the table-side and the MLP update -> one launch for all groups
             self.opt_local = HipAdamW(groups + [mlp_group], clear_grads=not self.keep_grads)
@@ -173,6 +188,7 @@ class HotPathTrainer:
         if self.cond_dims:
             cond_table = (self.cond_param.data if self.cond_param is not None else st.conditions).contiguous()
         tfs = self.tfs.data
+        table = self._latent_table()
         main = torch.cuda.current_stream(self.device)
         use_cw = self.class_w is not None and self.seg_weight > 0
         grouped = st.group_chunk > 0 and lo % st.group_chunk == 0 and hi - lo <= st.group_chunk
@@ -182,27 +198,27 @@ class HotPathTrainer:
             cond = cond_table[subj.long()].contiguous()  # generic K1 entry: per-sample rows (the grouped one gathers in the kernel)
         one_head = fast_k1 and eng.can_skip_saved()      # grouped batch on the activation-stationary bf16 path
         # nodes path: FiLM modulation from per-subject node tables (conditions are per subject here)
-        use_nodes = grouped and E.nodes_eligible(eng, tuple(self.latents.shape))
+        use_nodes = grouped and self.conv is None and E.nodes_eligible(eng, tuple(self.latents.shape))
         if use_nodes:
             return self._step_nodes(lo, hi)
 
         def k1_fwd():
             if fast_k1:
-                E.k1_forward_sorted(eng, coords, subj, self.latents.data, cond_table, tfs, n, cond_by_subject=True)
+                E.k1_forward_sorted(eng, coords, subj, table, cond_table, tfs, n, cond_by_subject=True)
             else:
-                E.k1_forward(eng, self.k1, coords, subj, self.latents.data, cond, tfs, False, n)
+                E.k1_forward(eng, self.k1, coords, subj, table, cond, tfs, False, n)
 
         def backward_only_prep():
             eng.pack(2)                                           # transposed linear_lats copies,
             if fast_k1:
-                E.k1_shadow(eng, self.k1, self.latents.data)      # node-major shadow (only the K1 backward reads it),
+                E.k1_shadow(eng, self.k1, table)                  # node-major shadow (only the K1 backward reads it),
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
                            self.prep_scratch)                     # cleared sums / dcoords + class-weight normaliser
 
         joined = True
         if one_head:
             # everything in front of the forward as ONE launch (cinema_step_head): no second stream, no join
-            E.step_head(eng, self.k1, coords, subj, self.latents.data, cond_table, tfs, n, cond_by_subject=True,
+            E.step_head(eng, self.k1, coords, subj, table, cond_table, tfs, n, cond_by_subject=True,
                         prepare=dict(dcoords=ws.dcoords, sums=self.sums, n_cls=self.n_cls, class_w=self.class_w if use_cw else None,
                                      voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch))
         elif self.side is not None:
@@ -241,7 +257,13 @@ class HotPathTrainer:
         _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
                                     tfs if want_tf else None, False, n, want_latents=True,
                                     want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
-                                    dlat_out=self.lat_grad, grouped=grouped, pending=pending)
+                                    dlat_out=self.lat_grad if self.conv is None else self.table_grad, grouped=grouped,
+                                    pending=pending)
+        work_conv = []
+        if self.conv is not None:
+            self._latent_table_backward()
+            if self.train_mlp and self.world > 1:
+                work_conv = [par.allreduce_mean_(prm.grad, self.pg, async_op=True) for prm in self.conv_params]
         if want_tf and self.tf_weight != 0.0:
             self._add_tf_regulariser_grad(subj, n)
         self.latents.grad = self.lat_grad
@@ -250,13 +272,36 @@ class HotPathTrainer:
         if self.cond_param is not None:
             self.cond_param.grad = self._cond_table_grad(subj, dcond, n, grouped)
         self.opt_local.step()
-        if work is not None:
-            work.wait()
+        for w in [work] + work_conv:
+            if w is not None:
+                w.wait()
         if self.opt_mlp is not None:
             self.opt_mlp.step()
         if self.train_mlp and not self.keep_grads:
             eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
         self.n_last = n
+
+    def _latent_table(self):
+        """What K1 interpolates: the latents, or their Conv3d modulation (one C-ABI call per step)."""
+        if self.conv is None:
+            return self.latents.data
+        a = self.args["inr_decoder"]
+        S, Cc, lx, ly, lz = self.latents.shape
+        _lib.check(self.eng.lib.cinema_conv_mod_forward(_lib.ptr(self.latents.data), _lib.ptr(self.conv.weight.data),
+                                                        _lib.ptr(self.conv.bias.data), S, Cc, lx, ly, lz, a["cnn_kernel_size"],
+                                                        self.eng.desc.precision, _lib.ptr(self.conv_work), _lib.ptr(self.table),
+                                                        self.eng.stream()), "cinema_conv_mod_forward")
+        return self.table
+
+    def _latent_table_backward(self):
+        """table gradient (left by the K1 backward in self.table_grad) -> latents, conv.weight, conv.bias gradients."""
+        a = self.args["inr_decoder"]
+        S, Cc, lx, ly, lz = self.latents.shape
+        _lib.check(self.eng.lib.cinema_conv_mod_backward(_lib.ptr(self.latents.data), _lib.ptr(self.conv.weight.data),
+                                                         _lib.ptr(self.table_grad), S, Cc, lx, ly, lz, a["cnn_kernel_size"],
+                                                         self.eng.desc.precision, _lib.ptr(self.conv_work), _lib.ptr(self.lat_grad),
+                                                         _lib.ptr(self.conv.weight.grad), _lib.ptr(self.conv.bias.grad),
+                                                         self.eng.stream()), "cinema_conv_mod_backward")
 
     def _cond_table_grad(self, subj, dcond, n: int, grouped: bool):
         """d loss / d conditions_val: the per-sample rows summed per subject (in the kernel for grouped batches)."""

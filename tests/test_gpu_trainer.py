@@ -359,6 +359,55 @@ def test_trainer_step_cfgV_full_shape(split):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_trainer_step_with_conv_modulator(precision):
+    """cnn_kernel_size = 3 (models/inr_decoder.py:109-123): K1 interpolates conv(latents); gradients of the latents, the
+    conv parameters and the MLP against the CPU oracle fed with torch's conv3d of the table, and the AdamW update of the
+    conv parameters in the MLP's group."""
+    import torch.nn.functional as F
+    from oracle import cinema_oracle as O
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    args = base_args([48, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, precision, tf_weight=0.0)
+    args["inr_decoder"]["cnn_kernel_size"] = 3
+    torch.manual_seed(77)
+    S, n = 5, 700
+    store = SubjectStore.synthetic(S, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=7, device=DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n)
+    tr = HotPathTrainer(args, store, DEV, keep_grads=True)
+    assert tr.conv is not None
+    with torch.no_grad():
+        tr.latents.mul_(10.0)                                   # N(0, 0.1): the conv output is not dominated by its bias
+        tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+    lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()
+    cw0, cb0 = tr.conv.weight.detach().cpu().clone(), tr.conv.bias.detach().cpu().clone()
+    coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
+    base = subj.long() * store.V + voxel
+    target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
+    lat_o, tf_o, cw, cb = (x.clone().requires_grad_(True) for x in (lat0, tf0, cw0, cb0))
+    cfg = dict(num_hidden_layers=3, omega=[30, 30], sr_dims=2, loss_metric="mse",
+               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0)
+    loss_o, _ = O.training_step(params, F.conv3d(lat_o, cw, cb, padding="same"), tf_o, coords, target, subj, None, cfg)
+    tr.step(0, n)
+    got = tr.loss_dict()
+    assert abs(got["total"] - float(loss_o["total"])) < tol * abs(float(loss_o["total"]))
+    errs = both_errs("glat", tr.lat_grad.cpu().numpy(), lat_o.grad.numpy())
+    errs.update(both_errs("gtf", tr.tf_grad.cpu().numpy(), tf_o.grad.numpy()))
+    errs.update(both_errs("g_conv_w", tr.conv.weight.grad.cpu().numpy(), cw.grad.numpy()))
+    errs.update(both_errs("g_conv_b", tr.conv.bias.grad.cpu().numpy(), cb.grad.numpy()))
+    gviews = tr.eng.param_views(tr.eng.flat_grad.cpu())
+    for k, p in params.items():
+        errs.update(both_errs("g_" + k, gviews[k].numpy(), p.grad.numpy()))
+    bad = failing(errs, tol, L2_TOL[precision])
+    assert not bad, bad
+    ref = torch.nn.Parameter(cw0.clone())
+    ref.grad = tr.conv.weight.grad.cpu()
+    torch.optim.AdamW([{"params": [ref], "lr": 1e-4, "weight_decay": 0.0}]).step()
+    assert rel_err(tr.conv.weight.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert not torch.equal(tr.conv.weight.detach().cpu(), cw0)
+
+
 def test_epoch_walks_the_whole_list_and_steps_the_schedule():
     """HotPathTrainer.epoch (build_atlas.py:65-68, 455-463): ceil(m / n_samples) steps including the ragged last one,
     every chunk grouped by subject (the grouped K1 kernels take them), cosine schedule stepped once per epoch."""
