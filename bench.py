@@ -389,6 +389,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args, trainer, n, lat0, tf0, flat0)
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()              # rank 0 times single kernels after the steps: leave together
         dist.destroy_process_group()
 
 
