@@ -1298,7 +1298,8 @@ struct SineLayerPlan {
 };
 
 bool sine_layer_plan(const cinema_sine_layer_desc *d, int64_t N, SineLayerPlan &p) {
-  if (!d || N < 1 || d->in_feat < 1 || d->out_feat < 16 || d->out_feat % 16 || d->lat_feat < 0) return false;
+  if (!d || N < 1 || N > (1L << 27) || d->in_feat < 1 || d->out_feat < 16 || d->out_feat % 16 || d->lat_feat < 0) return false;
+  if (d->in_feat > 8192 || d->out_feat > 8192 || d->lat_feat > 8192) return false;
   if (d->precision != CINEMA_PREC_F32 && d->precision != CINEMA_PREC_BF16) return false;
   p.H = d->out_feat; p.HP = round_up(p.H, 64);
   p.K = d->in_feat; p.small = p.K <= 3; p.KP = round_up(p.K, 64);
@@ -1475,7 +1476,7 @@ int sine_layer_backward_impl(const cinema_sine_layer_desc *d, const SineLayerPla
 extern "C" int64_t cinema_sine_layer_work_bytes(const cinema_sine_layer_desc *d, int64_t N) {
   SineLayerPlan p;
   if (!sine_layer_plan(d, N, p)) {
-    cinema_set_error("cinema_sine_layer_work_bytes: need N >= 1, in_feat >= 1, out_feat a multiple of 16, lat_feat >= 0, a valid precision");
+    cinema_set_error("cinema_sine_layer_work_bytes: need 1 <= N <= 2^27, in_feat >= 1, out_feat a multiple of 16, lat_feat >= 0 (all <= 8192), a valid precision");
     return -1;
   }
   return (int64_t)p.bytes;
@@ -1600,7 +1601,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_finish(const float *dW2, con
 }
 
 bool conv_geom(int64_t S, int C, int lx, int ly, int lz, int k, ConvGeom &g) {
-  if (S < 1 || C < 8 || C % 8 || lx < 1 || ly < 1 || lz < 1 || k < 1 || !(k & 1) || (long)lx * ly * lz > 4096) return false;
+  if (S < 1 || C < 8 || C % 8 || C > 4096 || lx < 1 || ly < 1 || lz < 1 || k < 1 || !(k & 1) || k > 15) return false;
+  if ((long)lx * ly * lz > 4096 || S * lx * ly * lz > (1L << 24)) return false;     // (s, n) rows are int in the GEMM engine
   g.S = (int)S; g.C = C; g.lx = lx; g.ly = ly; g.lz = lz; g.k = k; g.G = lx * ly * lz; g.K3 = k * k * k;
   g.R = ((long)S * g.G + 127) / 128 * 128;
   g.KK = (long)g.K3 * C;
@@ -1686,7 +1688,7 @@ int conv_backward_impl(const ConvGeom &g, const ConvWork &w, const float *in, co
 extern "C" int64_t cinema_conv_mod_work_bytes(int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t k, int32_t precision) {
   ConvGeom g;
   if (!conv_geom(S, C, lx, ly, lz, k, g) || (precision != CINEMA_PREC_F32 && precision != CINEMA_PREC_BF16)) {
-    cinema_set_error("cinema_conv_mod_work_bytes: need S >= 1, C a multiple of 8, an odd kernel size, a valid precision");
+    cinema_set_error("cinema_conv_mod_work_bytes: need S >= 1, C a multiple of 8 (<= 4096), an odd kernel size <= 15, at most 4096 nodes per subject and 2^24 in all, a valid precision");
     return -1;
   }
   return (int64_t)conv_work(g, precision).bytes;
@@ -1697,6 +1699,7 @@ extern "C" int cinema_conv_mod_forward(const float *in, const float *W, const fl
                                        void *stream) {
   ConvGeom g;
   CINEMA_REQUIRE(conv_geom(S, C, lx, ly, lz, k, g), "cinema_conv_mod_forward: bad shape (see cinema_conv_mod_work_bytes)");
+  CINEMA_REQUIRE(precision == CINEMA_PREC_F32 || precision == CINEMA_PREC_BF16, "cinema_conv_mod_forward: precision %d", (int)precision);
   CINEMA_REQUIRE(in && W && b && work && out, "cinema_conv_mod_forward: null argument");
   const ConvWork w = conv_work(g, precision);
   return precision == CINEMA_PREC_BF16 ? conv_forward_impl<bf16_t>(g, w, in, W, b, work, out, (hipStream_t)stream)
@@ -1708,6 +1711,7 @@ extern "C" int cinema_conv_mod_backward(const float *in, const float *W, const f
                                         float *dW, float *db, void *stream) {
   ConvGeom g;
   CINEMA_REQUIRE(conv_geom(S, C, lx, ly, lz, k, g), "cinema_conv_mod_backward: bad shape (see cinema_conv_mod_work_bytes)");
+  CINEMA_REQUIRE(precision == CINEMA_PREC_F32 || precision == CINEMA_PREC_BF16, "cinema_conv_mod_backward: precision %d", (int)precision);
   CINEMA_REQUIRE(in && W && dout && work && din && dW && db, "cinema_conv_mod_backward: null argument");
   const ConvWork w = conv_work(g, precision);
   return precision == CINEMA_PREC_BF16 ? conv_backward_impl<bf16_t>(g, w, in, W, dout, work, din, dW, db, (hipStream_t)stream)

@@ -79,3 +79,29 @@ def test_engine_refuses_cpu():
     d = E.make_desc(3, 32, 11, 128, 4, [1, 3], 30, 30, _lib.PREC_BF16)
     with pytest.raises(_lib.CinemaHipError):
         E.SirenEngine(d, "cpu")
+
+
+def test_work_size_queries_validate_their_arguments():
+    """The two size queries are host-only arithmetic: good shapes give a positive size, bad ones -1 + a message, and the
+    compute entry points refuse the same shapes before they touch the device."""
+    import ctypes as C
+    from cinema_amd import _lib
+    lib = _lib.load()
+    assert lib.cinema_conv_mod_work_bytes(64, 256, 3, 3, 3, 3, _lib.PREC_BF16) > 0
+    for bad in [(0, 256, 3, 3, 3, 3, _lib.PREC_BF16), (64, 250, 3, 3, 3, 3, _lib.PREC_BF16),      # S, C % 8
+                (64, 256, 3, 3, 3, 2, _lib.PREC_BF16), (64, 256, 3, 3, 3, 3, 7),                   # even kernel, precision
+                (64, 256, 17, 17, 17, 3, _lib.PREC_F32), (1 << 22, 256, 3, 3, 3, 3, _lib.PREC_F32)]:   # too many nodes
+        assert lib.cinema_conv_mod_work_bytes(*bad) == -1
+        assert b"cinema_conv_mod_work_bytes" in lib.cinema_last_error()
+    assert lib.cinema_conv_mod_forward(None, None, None, 64, 256, 3, 3, 3, 2, _lib.PREC_BF16, None, None, None) != 0
+    assert lib.cinema_conv_mod_forward(None, None, None, 64, 256, 3, 3, 3, 3, 7, None, None, None) != 0
+    assert lib.cinema_conv_mod_backward(None, None, None, 64, 256, 3, 3, 3, 3, _lib.PREC_BF16, None, None, None, None, None) != 0
+    d = _lib.SineLayerDesc(512, 256, 512, _lib.PREC_BF16, 30.0)
+    assert lib.cinema_sine_layer_work_bytes(C.byref(d), 1000) > 0
+    for f, v in [("out_feat", 500), ("in_feat", 0), ("lat_feat", -1), ("precision", 9), ("out_feat", 1 << 14)]:
+        e = _lib.SineLayerDesc(512, 256, 512, _lib.PREC_BF16, 30.0)
+        setattr(e, f, v)
+        assert lib.cinema_sine_layer_work_bytes(C.byref(e), 1000) == -1
+    assert lib.cinema_sine_layer_work_bytes(C.byref(d), 0) == -1
+    assert lib.cinema_sine_layer_work_bytes(C.byref(d), 1 << 28) == -1
+    assert lib.cinema_sine_layer_forward(C.byref(d), None, None, None, None, None, None, 1000, None, None, None) != 0
