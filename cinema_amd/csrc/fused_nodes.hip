@@ -82,7 +82,7 @@ struct NodesFwdArgs {
   int xrow, xsteps;
 };
 
-template <int NST>
+template <int NST, bool KEEP>
 __device__ __forceinline__ void nodes_fwd_body(const NodesFwdArgs &a, const long t0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *xs = (lds_char *)smem;                         // x tile [NST*16][xrow] bf16, swizzled
@@ -101,7 +101,7 @@ __device__ __forceinline__ void nodes_fwd_body(const NodesFwdArgs &a, const long
   const unsigned lane16 = lane * 16;
   const unsigned toff = (i * a.HP + fb) * 2u;
   const unsigned rowb = a.HP * 2u;
-  const bool keep = a.saved != nullptr;
+  constexpr bool keep = KEEP;              // false (dense inference): no cos, no conversions, no store addresses
   {
     const u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -297,10 +297,10 @@ __device__ __forceinline__ void nodes_fwd_body(const NodesFwdArgs &a, const long
   }
 }
 
-template <int BIG>
+template <int BIG, bool KEEP>
 __global__ __launch_bounds__(512) void k_nodes_fwd(NodesFwdArgs a) {
-  if ((int)blockIdx.x < a.g_big) nodes_fwd_body<BIG>(a, (long)BIG * blockIdx.x);
-  else nodes_fwd_body<BIG - 1>(a, (long)BIG * a.g_big + (long)(BIG - 1) * ((int)blockIdx.x - a.g_big));
+  if ((int)blockIdx.x < a.g_big) nodes_fwd_body<BIG, KEEP>(a, (long)BIG * blockIdx.x);
+  else nodes_fwd_body<BIG - 1, KEEP>(a, (long)BIG * a.g_big + (long)(BIG - 1) * ((int)blockIdx.x - a.g_big));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -582,8 +582,7 @@ static inline int ksteps_h(int k) { return ((k / 32) + FUSED_RING - 1) / FUSED_R
 // Launch plan: `units` 16-sample tiles over workgroups of BIG or BIG - 1 tiles, ONE launch.  A workgroup's time is its
 // weight stream (independent of its sample count) plus the epilogues of its samples, so the plan aims at the fewest
 // chip fillings: measured at cfg-D: 4-tile workgroups (0 spills) beat 6/7-tile ones (fewer weight streams, but spills): default 4, CINEMA_NODES_BIG=4..7.
-static void nodes_launch_plan(int64_t Npad, int64_t S, int *big, int *g_big, int *g_small) {
-  static const int bigmax = [] { const char *e = getenv("CINEMA_NODES_BIG"); const int v = e ? atoi(e) : 4; return v < 4 ? 4 : (v > 7 ? 7 : v); }();
+static void nodes_launch_plan(int64_t Npad, int64_t S, int bigmax, int *big, int *g_big, int *g_small) {
   const long units = Npad / 16 + std::min<long>(S, Npad);      // upper bound of the tile count (cinema_node_tiles)
   const long ncu = cinema_cu_count();
   const long rounds = (units + bigmax * ncu - 1) / (bigmax * ncu);
@@ -596,6 +595,10 @@ static void nodes_launch_plan(int64_t Npad, int64_t S, int *big, int *g_big, int
   *g_big = (int)(nwg - *g_small);
 }
 
+static int nodes_big_default() {
+  static const int v = [] { const char *e = getenv("CINEMA_NODES_BIG"); const int x = e ? atoi(e) : 4; return x < 4 ? 4 : (x > 7 ? 7 : x); }();
+  return v;
+}
 static int nodes_lds_fwd(const cinema_siren_desc *d, int nst, int lb_total) {
   return nst * 16 * 64 * ksteps_h(d->HP) + nst * 16 * (64 + 16) + 4 * (lb_total + 4 * d->HP);
 }
@@ -605,12 +608,16 @@ static int nodes_lds_bwd(const cinema_siren_desc *d, int nst) {
   return nst * 16 * xrow + nst * 16 * (64 + 16) + 16 * d->HP + (xrow == d->HP * 2 && top <= nst * 16 * xrow ? 0 : top);
 }
 
-template <int BIG>
-static int launch_nodes_fwd(const NodesFwdArgs &a, int grid, int smem, hipStream_t s) {
-  CINEMA_SMEM_ATTR(k_nodes_fwd<BIG>, smem);
-  hipLaunchKernelGGL(k_nodes_fwd<BIG>, dim3((unsigned)grid), dim3(512), smem, s, a);
+template <int BIG, bool KEEP>
+static int launch_nodes_fwd_k(const NodesFwdArgs &a, int grid, int smem, hipStream_t s) {
+  CINEMA_SMEM_ATTR((k_nodes_fwd<BIG, KEEP>), smem);
+  hipLaunchKernelGGL((k_nodes_fwd<BIG, KEEP>), dim3((unsigned)grid), dim3(512), smem, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
+}
+template <int BIG>
+static int launch_nodes_fwd(const NodesFwdArgs &a, int grid, int smem, hipStream_t s) {
+  return a.saved != nullptr ? launch_nodes_fwd_k<BIG, true>(a, grid, smem, s) : launch_nodes_fwd_k<BIG, false>(a, grid, smem, s);
 }
 template <int BIG>
 static int launch_nodes_bwd(const NodesBwdArgs &a, int grid, int smem, hipStream_t s) {
@@ -653,9 +660,9 @@ int nodes_forward(const cinema_siren_desc *d, const float *params, const void *p
   a.wf = (const bf16_t *)packed + d->pk_wf; a.bf = params + d->off_bf; a.out = out;
   a.xsteps = ksteps_h(d->HP); a.xrow = 64 * a.xsteps;
   int big, g_small;
-  nodes_launch_plan(Npad, S, &big, &a.g_big, &g_small);
-  a.nst_big = big;
   (void)N;
+  nodes_launch_plan(Npad, S, nodes_big_default(), &big, &a.g_big, &g_small);
+  a.nst_big = big;
   const int smem = nodes_lds_fwd(d, big, a.lb_total);
   CINEMA_REQUIRE(smem <= 160 * 1024, "nodes_forward: LDS budget exceeded (%d bytes, tiles of %d)", smem, big);
   const int grid = a.g_big + g_small;
@@ -696,7 +703,7 @@ int nodes_backward_chain(const cinema_siren_desc *d, const void *packed, const f
   a.out_dim = d->out_dim; a.xsteps = ksteps_h(d->HP); a.xrow = 64 * a.xsteps;
   a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
   int big, g_small;
-  nodes_launch_plan(Npad, S, &big, &a.g_big, &g_small);
+  nodes_launch_plan(Npad, S, nodes_big_default(), &big, &a.g_big, &g_small);
   a.nst_big = big;
   const int smem = nodes_lds_bwd(d, big);
   CINEMA_REQUIRE(smem <= 160 * 1024, "nodes_backward_chain: LDS budget exceeded (%d bytes, tiles of %d)", smem, big);
