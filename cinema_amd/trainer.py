@@ -12,6 +12,8 @@ K1 bwd -> optimiser.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Dict, List, Optional, Sequence
@@ -407,6 +409,63 @@ class HotPathTrainer:
         for s in self.schedulers:
             s.step()
         return steps
+
+    # ------------------------------------------------------------------------------------
+    # state (build_atlas.py:344-370, 427-430)
+    def checkpoint_dict(self, epoch: int) -> dict:
+        """The reference's checkpoint dictionary (build_atlas.py:347-355) without its two pandas frames (`tsv_file`,
+        `dataset_df`: subject selection is outside this package): tensors and plain containers only, so the file loads with
+        `torch.load(weights_only=True)`.  Under a process group the tables of all ranks, in rank order (collective)."""
+        return {"epoch": int(epoch),
+                "latents": par.gather_rows(self.latents.data, self.pg).cpu(),
+                "transformations": par.gather_rows(self.tfs.data, self.pg).cpu(),
+                "inr_decoder": {k: v.detach().cpu().clone() for k, v in self.decoder.state_dict().items()},
+                "args": self.args}
+
+    def save_state(self, epoch: int, log_dir: Optional[str] = None) -> Optional[str]:
+        """checkpoint_epoch_{epoch}.pth in `log_dir` (default args['output_dir']), written by rank 0; honours
+        args['save_model'] like the reference."""
+        if not self.args.get("save_model", True):
+            return None
+        st = self.checkpoint_dict(epoch)
+        path = os.path.join(log_dir if log_dir is not None else self.args["output_dir"], f"checkpoint_epoch_{epoch}.pth")
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(st, path)
+        return path
+
+    def load_checkpoint(self, chkp_path: str, epoch: int) -> dict:
+        """build_atlas.py:360-370: decoder weights and this rank's rows of the tables from checkpoint_epoch_{epoch}.pth;
+        the optimiser starts fresh (build_atlas.py:385).  The file is read with `weights_only=True`: a checkpoint written
+        by the reference itself carries pickled pandas frames and is refused by that loader -- re-save it without them."""
+        path = os.path.join(chkp_path, f"checkpoint_epoch_{epoch}.pth")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"State file {path} not found!")
+        chkp = torch.load(path, map_location="cpu", weights_only=True)
+        S = self.latents.shape[0]
+        sizes = par.gather_rows(torch.tensor([[S]], dtype=torch.int64, device=self.device), self.pg).flatten().tolist()
+        lo = sum(sizes[:self.rank])
+        lat, tfs = chkp["latents"], chkp["transformations"]
+        if lat.shape[0] != sum(sizes) or tuple(lat.shape[1:]) != tuple(self.latents.shape[1:]) or \
+                tuple(tfs.shape) != (sum(sizes), self.tfs.shape[1]):
+            raise ValueError(f"checkpoint tables {tuple(lat.shape)}, {tuple(tfs.shape)} do not fit {sum(sizes)} subjects of "
+                             f"{tuple(self.latents.shape[1:])} / {self.tfs.shape[1]}")
+        self.decoder.load_state_dict(chkp["inr_decoder"])       # copies into the views of the flat parameter buffer
+        with torch.no_grad():
+            self.latents.data.copy_(lat[lo:lo + S])
+            self.tfs.data.copy_(tfs[lo:lo + S])
+        for opt in (self.opt_local, self.opt_mlp):
+            if opt is not None:
+                opt.state.clear()
+        return chkp
+
+    def re_init_latents(self):
+        """build_atlas.py:427-430."""
+        with torch.no_grad():
+            self.latents.data.normal_(0, 0.01)
+            self.tfs.data.zero_()
+        for g in (self.lat_grad, self.tf_grad, self.eng.flat_grad):
+            g.zero_()
 
     def loss_dict(self) -> Dict[str, float]:
         """Losses of the LAST step with the reference's keys (one device->host sync; call every k steps)."""

@@ -482,3 +482,45 @@ def test_step_head_equals_the_separate_launches():
     assert torch.equal(st_a.shadow, st_b.shadow)
     assert torch.equal(sums_a, sums_b) and float(sums_a[2]) > 0 and float(sums_a[0]) == 0.0
     assert float(scratch[256:].abs().max()) == 0.0          # the arrival counter was reset
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """save_state / load_checkpoint (build_atlas.py:344-370): the reference's keys without the pandas frames, readable
+    with weights_only=True; a fresh trainer that loads it holds the same decoder and tables, starts with a fresh
+    optimiser, and its next step equals the next step of a trainer built from the same state by hand."""
+    import os
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([32, 3, 3, 3], 128, 3, [1, 3], [2, 10], 0, "bf16")
+    args.update(output_dir=str(tmp_path), save_model=True)
+    torch.manual_seed(2)
+    store = SubjectStore.synthetic(4, (24, 24, 24), 155.0 / 24, [155, 155, 155], 2, 10, seed=3, device=DEV)
+    tr = HotPathTrainer(args, store, DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(4), group_chunk=1500)
+    for i in range(3):
+        tr.step(i * 1500, (i + 1) * 1500)
+    path = tr.save_state(7)
+    assert os.path.basename(path) == "checkpoint_epoch_7.pth"
+    chk = torch.load(path, weights_only=True)
+    assert set(chk) == {"epoch", "latents", "transformations", "inr_decoder", "args"} and chk["epoch"] == 7
+    assert list(chk["inr_decoder"])[0] == "sr_net.final_linear.weight"          # reference's state_dict order
+    torch.manual_seed(99)
+    tr2 = HotPathTrainer(args, store, DEV)                                       # different initialisation
+    assert not torch.equal(tr2.eng.flat, tr.eng.flat)
+    tr2.step(0, 1500)                                                            # gives its optimiser a history to forget
+    tr2.load_checkpoint(str(tmp_path), 7)
+    assert torch.equal(tr2.eng.flat, tr.eng.flat) and torch.equal(tr2.latents, tr.latents) and torch.equal(tr2.tfs, tr.tfs)
+    assert len(tr2.opt_local.state) == 0
+    # reference semantics after a load: same parameters, NEW optimiser -> compare with a trainer set up that way by hand
+    tr3 = HotPathTrainer(args, store, DEV)
+    with torch.no_grad():
+        tr3.eng.flat.copy_(tr.eng.flat); tr3.latents.copy_(tr.latents); tr3.tfs.copy_(tr.tfs)
+    tr2.step(4500, 6000)
+    tr3.step(4500, 6000)
+    for name, x, y in (("flat", tr3.eng.flat, tr2.eng.flat), ("lat", tr3.latents, tr2.latents), ("tfs", tr3.tfs, tr2.tfs)):
+        assert rel_err(y.detach().cpu().numpy(), x.detach().cpu().numpy()) < 1e-4, name
+    with pytest.raises(FileNotFoundError):
+        tr2.load_checkpoint(str(tmp_path), 8)
+    args["save_model"] = False
+    assert tr.save_state(9) is None and not os.path.exists(os.path.join(str(tmp_path), "checkpoint_epoch_9.pth"))
+    tr.re_init_latents()
+    assert float(tr.tfs.detach().abs().max()) == 0.0 and 0.005 < float(tr.latents.detach().std()) < 0.02
