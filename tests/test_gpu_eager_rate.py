@@ -1,0 +1,107 @@
+"""What the reference's OWN method reaches on this GPU ("reference fp32 PyTorch path on GPU"): its
+optimisation step (build_atlas.py:69-90) written with stock PyTorch-ROCm ops and run eagerly on cuda:0 at the bench
+shape (cfg-D, 64 subjects, N = 25 000, hidden 512), beside HotPathTrainer.step on the same shape.  Two formulations of
+the eager step: (a) the reference's, which gathers one latent grid per SAMPLE (`latents[idcs_df]`, inr_decoder.py:33 =
+691 MB) and calls F.grid_sample (inr_decoder.py:80-82); (b) the oracle's leaner restatement (8 corner gathers).  fp32 and
+autocast + GradScaler as args['amp'] does (build_atlas.py:76-85).  The rates are printed (pytest -s shows them; DESIGN.md
+section 7 quotes them); the assertion only guards the order of magnitude."""
+import os
+import sys
+import time
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(__file__))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S, N, C, H, LAYERS, MOD = 64, 25000, 256, 512, 5, [1, 3, 5]
+
+
+def _eager_rate(amp: bool, materialise: bool, steps: int = 8, warm: int = 3) -> float:
+    from oracle import cinema_oracle as O
+    g = torch.Generator().manual_seed(42)
+    params = {k: v.to(DEV).requires_grad_() for k, v in O.init_siren_params(3, C, 12, H, LAYERS, 30.0, 30.0, MOD, g).items()}
+    assert sum(p.numel() for p in params.values()) == 2114060                    # cfg-D parameter count
+    latents = (torch.randn(S, C, 3, 3, 3, generator=g) * 0.01).to(DEV).requires_grad_()
+    tf_table = torch.zeros(S, 6, device=DEV, requires_grad=True)
+    coords = ((torch.rand(N, 3, generator=g) * 1.8 - 0.9)).to(DEV)
+    subj = torch.sort(torch.randint(0, S, (N,), generator=g))[0].to(DEV)
+    target = torch.cat((torch.rand(N, 2, generator=g), torch.randint(0, 10, (N, 1), generator=g).float()), dim=1).to(DEV)
+    opt = torch.optim.AdamW([{"params": [latents], "lr": 1e-3}, {"params": [tf_table], "lr": 1e-4},
+                             {"params": list(params.values()), "lr": 1e-4}])
+    scaler = torch.amp.GradScaler("cuda") if amp else None
+
+    def step():
+        opt.zero_grad()
+        with torch.autocast(device_type="cuda", enabled=amp):
+            tfs = tf_table[subj]
+            c = O.register_coords(coords, tfs)
+            if materialise:
+                grids = latents[subj]                                                # (N, C, 3, 3, 3): inr_decoder.py:33
+                lat = F.grid_sample(grids, c[:, None, None, None, :], mode="bilinear", align_corners=True,
+                                    padding_mode="border").squeeze()                 # inr_decoder.py:80-82
+            else:
+                lat = O.trilinear_latent(c, latents, subj)
+            out = O.siren_forward(params, c, lat, LAYERS, 30.0, 30.0)
+            loss = O.criterion(out.float(), target, tfs, 2, "mse", None, 1e-3)
+        if amp:
+            scaler.scale(loss["total"]).backward()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            loss["total"].backward()
+            opt.step()
+        return loss["total"].item()                                                  # build_atlas.py:90
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    assert last == last
+    return N / dt
+
+
+def _hot_path_rate(steps: int = 200, warm: int = 30) -> float:
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = {
+        "inr_decoder": {"in_dim": 3, "out_dim": [2, 10], "latent_dim": [C, 3, 3, 3], "cond_dims": 0, "hidden_size": H,
+                        "num_hidden_layers": LAYERS, "modulated_layers": MOD, "omega": [30, 30], "cnn_kernel_size": 0,
+                        "tf_dim": 6, "precision": "bf16"},
+        "optimizer": {"lr_latent": 1e-3, "lr_tf": 1e-4, "lr_inr": 1e-4, "latent_weight_decay": 0.0, "tf_weight_decay": 0.0,
+                      "inr_weight_decay": 0.0, "seg_weight": 1.0, "tf_weight": 1e-3, "loss_metric": "mse", "scheduler": {"type": None}},
+        "dataset": {"class_weights": None, "label_names": []}, "epochs": {"train": 1, "val": 1}, "device": DEV,
+    }
+    store = SubjectStore.synthetic(S, (32, 32, 32), 155.0 / 32, [155, 155, 155], 2, 10, seed=3, device=DEV)
+    tr = HotPathTrainer(args, store, DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(4), group_chunk=N)
+    m = len(store) // N
+    assert m >= 1
+    for i in range(warm):
+        tr.step((i % m) * N, (i % m + 1) * N)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(steps):
+        tr.step((i % m) * N, (i % m + 1) * N)
+    torch.cuda.synchronize()
+    return N / ((time.perf_counter() - t) / steps)
+
+
+def test_hot_path_against_the_eager_pytorch_step():
+    rows = [("eager fp32, per-sample grids + grid_sample (the reference's formulation)", _eager_rate(False, True)),
+            ("eager autocast + GradScaler, per-sample grids + grid_sample", _eager_rate(True, True)),
+            ("eager fp32, 8 corner gathers (oracle restatement)", _eager_rate(False, False)),
+            ("eager autocast + GradScaler, 8 corner gathers", _eager_rate(True, False))]
+    ours = _hot_path_rate()
+    best = max(r for _, r in rows)
+    for name, r in rows:
+        print(f"[eager-rate] {name}: {r / 1e6:.3f} M samples/s", flush=True)
+    print(f"[eager-rate] HotPathTrainer.step (bf16): {ours / 1e6:.2f} M samples/s = {ours / best:.1f} x the fastest eager step",
+          flush=True)
+    assert ours > 2.0 * best
