@@ -205,7 +205,13 @@ def rooflines(trainer, n, opt, peak):
                     "avg_launch_ms": ms, "bytes_per_sample": bytes_ps})
     trainer.lat_grad.zero_()
     trainer.tf_grad.zero_()
-    return objs, siren_total, hbm_view, hbm
+
+    def optimiser():
+        trainer.opt_local.step()
+        if trainer.opt_mlp is not None:
+            trainer.opt_mlp.step()
+    opt_ms = event_ms(optimiser, reps)          # the rate is reported with and without the optimiser step
+    return objs, siren_total, hbm_view, hbm, opt_ms
 
 
 def run_atlas(opt, dev):
@@ -358,9 +364,9 @@ def main():
     losses = trainer.loss_dict()
 
     peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-    siren = siren_total = hbm_view = hbm = peaks = None
+    siren = siren_total = hbm_view = hbm = peaks = opt_ms = None
     if rank == 0 and not opt.profile_step:
-        siren, siren_total, hbm_view, hbm = rooflines(trainer, n, opt, peak)
+        siren, siren_total, hbm_view, hbm, opt_ms = rooflines(trainer, n, opt, peak)
         peaks = box_peaks(dev)
 
     fwd_f, tot_f = flops_per_sample()
@@ -385,6 +391,9 @@ def main():
             res["roofline_hbm_view"] = hbm_view
             res["roofline_hbm_kernels"] = hbm
             res["box_peaks"] = peaks
+            ms = res["ms_per_step"]
+            res["optimiser_ms"] = opt_ms                     # the fused AdamW launch(es), timed alone
+            res["value_without_optimiser"] = world * n / ((ms - opt_ms) * 1e-3)
         if world == 1 and not opt.no_cpu_baseline and not opt.profile_step:
             res["cpu_baseline"] = cpu_baseline(args, trainer, n, lat0, tf0, flat0)
         print(json.dumps(res))
