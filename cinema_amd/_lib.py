@@ -90,6 +90,12 @@ SIGNATURES = {
     "cinema_siren_forward_nodes": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _P],
     "cinema_siren_backward_nodes": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _P, _P, _P,
                                     _I32, _P, _P],
+    "cinema_nodegrad_eligible": [C.POINTER(SirenDesc), _I32, _I32, _I32],
+    "cinema_nodegrad_work_bytes": [C.POINTER(SirenDesc), _I64, _I64],
+    "cinema_nodegrad_prepare": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
+                                _P, _P],
+    "cinema_siren_backward_nodegrad": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _I32,
+                                       _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_prepared": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd_normed": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P, _P],
@@ -107,7 +113,8 @@ SIGNATURES = {
     "cinema_infer_rescale": [_P, _I64, _I32, _I32, _P, _P],
     "cinema_grid_coords": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
 }
-_RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64, "cinema_conv_mod_work_bytes": C.c_int64}
+_RESTYPES = {"cinema_last_error": C.c_char_p, "cinema_sine_layer_work_bytes": C.c_int64, "cinema_conv_mod_work_bytes": C.c_int64,
+             "cinema_nodegrad_work_bytes": C.c_int64}
 
 _lib = None
 

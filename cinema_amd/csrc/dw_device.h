@@ -3,7 +3,10 @@
 // kernel: the two are independent, k_bwd_coord_reduce).  Included INSIDE the anonymous namespace of each translation unit.
 #pragma once
 
-struct DwProb { const void *P; const void *Q; float *out; int ldp, ldq, ldo, M, K, tk; };
+// rows / nsplit / wg0 / slab0 are read by the 256 x 256 kernels only (k_dw256, dw256_reduce_body): a problem reduces over
+// its own `rows` sample (or node) rows, cut into `nsplit` ranges; its workgroups are [wg0, wg0 + tiles * nsplit) and its
+// partial tiles start at slab index slab0 (tile-major, split innermost).  k_dw_grouped uses the common splitk / Npad.
+struct DwProb { const void *P; const void *Q; float *out; int ldp, ldq, ldo, M, K, tk; int rows, nsplit, wg0, slab0; };
 struct DwArgs {
   DwProb p[3 * CINEMA_MAX_LAYERS + 2];
   int tile_start[3 * CINEMA_MAX_LAYERS + 3];
@@ -23,8 +26,8 @@ __device__ __forceinline__ void dw256_reduce_body(const Dw256Args &a, int vbid) 
   const int row = rb * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 8;
   if (h0 + row >= pr.M || c0 + col >= pr.K) return;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  const float *src = a.slab + (size_t)tg * a.g.splitk * (256 * 256) + row * 256 + col;
-  for (int sp = 0; sp < a.g.splitk; ++sp) {
+  const float *src = a.slab + ((size_t)pr.slab0 + (size_t)t * pr.nsplit) * (256 * 256) + row * 256 + col;
+  for (int sp = 0; sp < pr.nsplit; ++sp) {
     s0 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256));
     s1 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256) + 4);
   }

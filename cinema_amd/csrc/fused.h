@@ -20,7 +20,8 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
                   const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s);
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
-                         hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr);
+                         hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr, bool lat_bias = true);
+// lat_bias = false: the linear_lats bias gradients are left to the caller (node gradients take them from dU)
 
 // "nodes" path (fused_nodes.hip, node.hip; layout in nodes.h): the same chain kernels with the FiLM modulation read from
 // per-subject node tables.  Its forward stream (pk_ns) holds the main weights only.

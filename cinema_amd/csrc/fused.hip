@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_pack_side(PackSideArgs a) { pack_side_b
 // stream (23 + 17 us in a row for the two the forward waits for) or need a second stream, whose join costs 6-10 us of
 // idle queue.  Block ranges: step_prepare (the longest chain of dependent loads; optional, g_pr = 0) | K1 forward chunks |
 // backward-only transposes (64 workgroups each) | weight streams | side block | shadow tiles (optional, g_nm = 0).
-#define HEAD_MAX_JOBS 8
+#define HEAD_MAX_JOBS 16
 struct StepHeadArgs {
   PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1;
   PackJob job[HEAD_MAX_JOBS]; void *packed;
@@ -410,6 +410,7 @@ struct FusedBwdArgs {
   const bf16_t *saved; long slot; int sv_c[CINEMA_MAX_LAYERS], sv_z[CINEMA_MAX_LAYERS], sv_s[CINEMA_MAX_LAYERS];
   bf16_t *gbuf; int gb_z[CINEMA_MAX_LAYERS], gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS];
   float *gp; long off_b[CINEMA_MAX_LAYERS], off_bl[CINEMA_MAX_LAYERS], off_w0; int wgrads;
+  int latb;                          // wgrads and the linear_lats bias gradients are wanted from this kernel
   float *dcoords;
   unsigned mod_mask; int n_layers, in_dim, H, HP, out_dim, xrow, xsteps;
   float om_first, om_hidden;
@@ -450,7 +451,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
             dz[j] = omega * gq * sj;
             ds[j] = omega * gq * zj;
           }
-          if (a.wgrads) {
+          if (a.latb) {
             ts += reduce16_scatter(ds, lane);
             tt += reduce16_scatter(dt, lane);
           }
@@ -511,7 +512,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
         const int fi = fb_l + reduce16_index(i_l);
         if (fi < a.H) atomicAdd(a.gp + a.off_b[l] + fi, tz);
         if constexpr (MOD) {
-          if (fi < a.H) {
+          if (fi < a.H && a.latb) {
             atomicAdd(a.gp + a.off_bl[l] + fi, ts);
             atomicAdd(a.gp + a.off_bl[l] + a.H + fi, tt);
           }
@@ -734,10 +735,13 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
   const int H = d->hidden, L = d->lat;
   for (int i = 0; i < d->n_layers; ++i)
     if ((d->modulated_mask >> i) & 1u) {
-      CINEMA_REQUIRE(nj + 2 <= HEAD_MAX_JOBS, "cinema_step_head: more than %d modulated layers", HEAD_MAX_JOBS / 2);
+      CINEMA_REQUIRE(nj + 4 <= HEAD_MAX_JOBS, "cinema_step_head: more than %d modulated layers", HEAD_MAX_JOBS / 4);
       const float *wl = params + d->off_wl[i];
       a.job[nj++] = PackJob{wl, d->pk_wlsT[i], H, L, L, d->LP, d->HP, 1};
       a.job[nj++] = PackJob{wl + (size_t)H * L, d->pk_wltT[i], H, L, L, d->LP, d->HP, 1};
+      // row-major copies: the node projections of cinema_nodegrad_prepare (cinema_siren_pack_part(.., 8))
+      a.job[nj++] = PackJob{wl, d->pk_wls[i], H, L, L, d->HP, d->LP, 0};
+      a.job[nj++] = PackJob{wl + (size_t)H * L, d->pk_wlt[i], H, L, L, d->HP, d->LP, 0};
     }
   a.packed = packed;
   a.g_job = 64 * nj;
@@ -828,7 +832,7 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
 
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *gp, float *dcoords, bool wgrads,
-                         hipStream_t s, void *dout16, float *dbf) {
+                         hipStream_t s, void *dout16, float *dbf, bool lat_bias) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_bs >= 0, "fused_backward_chain: descriptor not planned for the fused path");
   CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_backward_chain: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
   FusedBwdArgs a = {};
@@ -843,7 +847,7 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
     a.off_b[i] = d->off_b[i]; a.off_bl[i] = d->off_bl[i];
   }
   a.off_w0 = d->off_w[0];
-  a.gp = gp; a.wgrads = wgrads ? 1 : 0; a.dcoords = dcoords;
+  a.gp = gp; a.wgrads = wgrads ? 1 : 0; a.latb = (wgrads && lat_bias) ? 1 : 0; a.dcoords = dcoords;
   a.mod_mask = d->modulated_mask; a.n_layers = d->n_layers; a.in_dim = d->in_dim; a.H = d->hidden; a.HP = d->HP;
   a.out_dim = d->out_dim; a.xsteps = ksteps(d->HP); a.xrow = 64 * a.xsteps;
   a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;

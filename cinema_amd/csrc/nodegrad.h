@@ -1,0 +1,53 @@
+// Node-space backward of the latent side ("node gradients"): internal interface between nodegrad.hip (its kernels) and
+// siren.hip (which sequences them inside the backward).
+//
+// The interpolated latent of a sample is a convex combination of its subject's grid nodes,
+//     lat[n] = sum_k w[n][k] * table[s][k]          (models/inr_decoder.py:73-85, grid_sample on a 3^3 grid)
+// and everything downstream of it up to the FiLM phase is linear (models/siren.py:32, :61).  So the three gradients
+// that leave the chain kernels through the per-sample rows X[n] = [ds_j | dt_j]_j (+ dOut) -- d linear_lats.weight,
+// d table and d coords (through the interpolation weights) -- only need
+//     dU[s][k][f]  = sum_{n of s} w[n][k] * X[n][f]        (32 node slots x F features per subject)
+//     dwn[n][k]    = sum_f X[n][f] * U'[s][k][f]           (U' = linear_lats(table[s][k] - mean_k table[s][k]))
+// k_node_grad reads X ONCE and forms both; the weight gradient, the table gradient and the bias gradient are then GEMMs
+// over S*32 node rows instead of N sample rows, and d coords = sum_k dwn[n][k] * d w[n][k] / d coords.
+//
+// Work buffer (caller-owned, cinema_nodegrad_work_bytes; zeroed once by the caller, rows >= S*32 stay zero):
+//   wt     bf16 [Npad/16][32][16]   interpolation weights, per 16-row block, slot-major (MFMA operand order)
+//   T      bf16 [Rp][LP]            node rows of the table (+ the subject's conditions), Rp = S*32 rounded up to 128
+//   Up     bf16 [S*32][F]           centred projections U', F = n_mod * 2 * HP
+//   Vp     bf16 [S*32][16]          the same through final_linear.weight[:, H:]
+//   dU     bf16 [Rp][F], dUo16 bf16 [Rp][16], dUo32 fp32 [Rp][16]
+//   dcn    fp32 [2 n_mod + 1][Npad][4]   per-tensor parts of d coords through the interpolation weights
+//   dT     fp32 [2 n_mod][Rp][LP]   per-segment parts of d (node rows)
+#pragma once
+#include "common.h"
+
+#define NG_SLOTS 32
+#define NG_ONE_SLOT 31
+
+struct NgPlan {
+  long S, Npad, Rp;
+  int n_mod, F, nparts, HP, LP;
+  int layer_of[CINEMA_MAX_LAYERS];
+  size_t wt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
+};
+bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz);
+NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad);
+
+// X -> dU, dUo, dcn (one launch).  gbuf: the backward scratch tensors (ds / dt slots, dOut16 in the last slot).
+int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, const void *gbuf, const float *coords_t,
+                   const int32_t *idx, int64_t N, int lx, int ly, int lz, hipStream_t s);
+
+// Tail of the backward in one launch (block ranges; NULL / 0 switches a range off):
+//   reduce:  split reduction of k_dw256's partial tiles (opaque Dw256Args, may be NULL)
+//   bias:    linear_lats.bias gradients from the constant-1 slot of dU (grad_params != NULL)
+//   table:   d table (S, C, G) and d cond table from the dT parts (dlatents != NULL)
+//   tf:      embedding-table gradient from d coords (dembed != NULL)
+struct NgTailArgsHost {
+  const void *reduce;            // const Dw256Args * or NULL
+  float *grad_params;            // flat gradient (bias range) or NULL
+  float *dlatents; float *dcond; // (S, C, G), (S, cond_dims) or NULL
+  float *dembed; const float *embed; int tf_dim; const float *coords; const float *dcoords; const int32_t *idx;
+  int64_t N; int C, G, cond_dims;
+};
+int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, const NgTailArgsHost &t, hipStream_t s);

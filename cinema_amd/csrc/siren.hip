@@ -2,6 +2,7 @@
 // Reference arithmetic: models/siren.py:26-36 (SineLayer.forward), :59-61 (Siren.forward).
 #include "gemm_engine.h"
 #include "fused.h"
+#include "nodegrad.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -41,10 +42,8 @@ struct TileCtx {
   int nrow[4];         // this lane's sample row for each sample tile st
 };
 
-__device__ __forceinline__ TileCtx make_ctx(int tiles_f) {
+__device__ __forceinline__ TileCtx make_ctx_id(int id, int tiles_f) {
   TileCtx c;
-  const int nwg = gridDim.x;
-  const int id = xcd_remap(blockIdx.x, nwg);
   c.f0 = (id % tiles_f) * 128;
   c.n0 = (id / tiles_f) * 128;
   const int tid = threadIdx.x;
@@ -59,6 +58,7 @@ __device__ __forceinline__ TileCtx make_ctx(int tiles_f) {
   for (int st = 0; st < 4; ++st) c.nrow[st] = c.n0 + c.wn * 64 + 16 * st + c.i;
   return c;
 }
+__device__ __forceinline__ TileCtx make_ctx(int tiles_f) { return make_ctx_id(xcd_remap(blockIdx.x, gridDim.x), tiles_f); }
 
 __device__ __forceinline__ void acc_fill(f32x4 (&acc)[4][4], const float (&v)[16]) {
 #pragma unroll
@@ -299,12 +299,24 @@ struct DlatArgs {
   const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;
   int lat; int LP; int ldg;
   float *out; int tiles_f;
+  int seg_split; long part_stride;   // seg_split: workgroup = (segment, tile), segment sg writes its own part out + sg * part_stride
 };
 
 template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileCtx c = make_ctx(a.tiles_f);
+  int sg0 = 0, ns = a.nseg;
+  float *out = a.out;
+  TileCtx c;
+  if (a.seg_split) {     // few rows (node space): the segments run side by side instead of in one k loop
+    const int ntile = gridDim.x / a.nseg;
+    sg0 = blockIdx.x / ntile;
+    c = make_ctx_id(blockIdx.x - sg0 * ntile, a.tiles_f);
+    ns = 1;
+    out += (size_t)sg0 * a.part_stride;
+  } else {
+    c = make_ctx(a.tiles_f);
+  }
   f32x4 acc[4][4];
   {
     float zero[16];
@@ -312,15 +324,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
     for (int j = 0; j < 16; ++j) zero[j] = 0.f;
     acc_fill(acc, zero);
   }
-  smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
-  nt_mainloop_segs<T>(acc, a.seg, a.nseg, c.f0, a.LP, c.n0, a.ldg, smem);
+  if (sg0 == 0) smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
+  nt_mainloop_segs<T>(acc, a.seg + sg0, ns, c.f0, a.LP, c.n0, a.ldg, smem);
   if (c.fb < a.LP) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = acc[j >> 2][st][j & 3];
-      store16(a.out + (size_t)c.nrow[st] * a.LP + c.fb, v);
+      store16(out + (size_t)c.nrow[st] * a.LP + c.fb, v);
     }
   }
 }
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
   const int rel = lid - a.tile_start[pi] * a.splitk;
   const int split = rel / ntp, t = rel - split * ntp;
   const int h0 = (t / pr.tk) * 128, c0 = (t % pr.tk) * 128;
-  const int ntile = a.Npad / E::BN;
+  const int ntile = (pr.rows ? pr.rows : a.Npad) / E::BN;
   const int nbeg = (int)((long)ntile * split / a.splitk) * E::BN;
   const int nend = (int)((long)ntile * (split + 1) / a.splitk) * E::BN;
   f32x4 acc[4][4];
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_dw_grouped(DwArgs a) {
 #define DW256_TILE (DW256_BN * DW256_ROWB)        // 16 KB per operand tile
 #define DW256_NBUF 4                              // tiles k+1..k+3 are in flight while tile k is multiplied
 #define DW256_SMEM (DW256_NBUF * 2 * DW256_TILE)  // 128 KB
-#define DW256_MAX_SPLIT 8
+#define DW256_MAX_SPLIT 12
 
 typedef __attribute__((address_space(1))) const void gmem_cvoid;
 
@@ -445,14 +457,14 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wh = wave >> 2, wk = wave & 3;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
-  while (pi + 1 < a.g.nprob && lid >= a.g.tile_start[pi + 1] * a.g.splitk) ++pi;
+  while (pi + 1 < a.g.nprob && lid >= a.g.p[pi + 1].wg0) ++pi;
   const DwProb pr = a.g.p[pi];
   const int ntp = a.g.tile_start[pi + 1] - a.g.tile_start[pi];
-  const int rel = lid - a.g.tile_start[pi] * a.g.splitk;
+  const int rel = lid - pr.wg0;
   const int split = rel / ntp, t = rel - split * ntp;
   const int h0 = (t / pr.tk) * 256, c0 = (t % pr.tk) * 256;
-  const int ntile = a.g.Npad / DW256_BN;
-  const int tbeg = (int)((long)ntile * split / a.g.splitk), tend = (int)((long)ntile * (split + 1) / a.g.splitk);
+  const int ntile = pr.rows / DW256_BN;
+  const int tbeg = (int)((long)ntile * split / pr.nsplit), tend = (int)((long)ntile * (split + 1) / pr.nsplit);
   f32x4 acc[8][4];
 #pragma unroll
   for (int x = 0; x < 8; ++x)
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(DW256_THREADS) void k_dw256(Dw256Args a) {
   }
   for (int k0 = 0; k0 < nt; k0 += 4) { DW256_SLOT(0) DW256_SLOT(1) DW256_SLOT(2) DW256_SLOT(3) }
 #undef DW256_SLOT
-  float *slab = a.slab + ((size_t)(a.g.tile_start[pi] + t) * a.g.splitk + split) * (256 * 256);
+  float *slab = a.slab + ((size_t)pr.slab0 + (size_t)t * pr.nsplit + split) * (256 * 256);
   const int g = lane >> 4, i = lane & 15;
 #pragma unroll
   for (int ht = 0; ht < 8; ++ht)
@@ -845,7 +857,7 @@ extern "C" int cinema_siren_plan(cinema_siren_desc *d) {
     for (int i = 1; i < d->n_layers; ++i) tiles += t256(H, H);
     for (int i = 0; i < d->n_layers; ++i)
       if ((d->modulated_mask >> i) & 1u) tiles += 2 * t256(H, L);
-    d->gb_extra_bytes = tiles * 8 /* DW256_MAX_SPLIT */ * 256 * 256 * 4 + 256;
+    d->gb_extra_bytes = tiles * 12 /* DW256_MAX_SPLIT */ * 256 * 256 * 4 + 256;
   }
   return 0;
 }
@@ -881,12 +893,13 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
   // W, W^T and the row-major linear_lats copies are only read by the layer-by-layer kernels
   const bool fwd_layered = fused_mode(d) == 0;
   const bool nodes = (part & 4) != 0;       // nodes path: forward stream without the linear_lats segments + row-major linear_lats
+  const bool rowmajor = (part & 8) != 0;    // node gradients: row-major linear_lats only (cinema_nodegrad_prepare)
   if (nodes && fwd_layered) { cinema_set_error("cinema_siren_pack_part: part 4 needs the activation-stationary bf16 path"); return -1; }
   if (!fwd_layered && (part & 1))
     if (int rc = fused_pack(d, params, packed, s)) return rc;     // weight streams, side block, padded final_linear
   if (nodes)
     if (int rc = fused_pack_nodes(d, params, packed, s)) return rc;
-  if (!fwd_layered && !(part & 2) && !nodes) return 0;
+  if (!fwd_layered && !(part & 2) && !nodes && !rowmajor) return 0;
   if (fwd_layered && !(part & 1)) return 0;
   for (int i = 0; i < d->n_layers; ++i) {
     if (i > 0) {
@@ -897,7 +910,7 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
     }
     if ((d->modulated_mask >> i) & 1u) {
       const float *wl = params + d->off_wl[i];
-      if (fwd_layered || nodes) {
+      if (fwd_layered || nodes || rowmajor) {
         if (int rc = add(wl, d->pk_wls[i], H, L, L, HP, LP, 0)) return rc;
         if (int rc = add(wl + (size_t)H * L, d->pk_wlt[i], H, L, L, HP, LP, 0)) return rc;
       }
@@ -920,7 +933,8 @@ static int pack_impl(const cinema_siren_desc *d, const float *params, void *pack
 extern "C" int cinema_siren_pack_part(const cinema_siren_desc *d, const float *params, void *packed, int32_t part,
                                       void *stream) {
   CINEMA_REQUIRE(d && params && packed, "cinema_siren_pack: null argument");
-  CINEMA_REQUIRE(part >= 1 && part <= 7, "cinema_siren_pack_part: part is a mask of 1 (forward), 2 (backward-only), 4 (nodes path)");
+  CINEMA_REQUIRE(part >= 1 && part <= 15, "cinema_siren_pack_part: part is a mask of 1 (forward), 2 (backward-only), 4 (nodes path), "
+                 "8 (row-major linear_lats for cinema_nodegrad_prepare)");
   hipStream_t s = (hipStream_t)stream;
   return d->precision == CINEMA_PREC_BF16 ? pack_impl<bf16_t>(d, params, packed, part, s)
                                           : pack_impl<float>(d, params, packed, part, s);
@@ -1021,12 +1035,17 @@ static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
 }
 
 struct NodesCtx { const void *wrows; const void *tiles; const void *U; int64_t S; int round_s; };
+// node-space backward of the latent side (nodegrad.h): what the K1 backward needs beside the SIREN's own arguments
+struct NgCtx {
+  void *work; const float *coords; const int32_t *idx; const float *embed; int tf_dim; int64_t S; int C, lx, ly, lz, cond_dims;
+  float *dlatents, *dembed, *dcond;
+};
 
 template <typename T>
 static int backward_impl(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
                          const void *lat, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
                          float *gp, float *dlat, float *dcoords, int32_t flags, hipStream_t s, Dw256Args *pending = nullptr,
-                         const NodesCtx *nodes = nullptr) {
+                         const NodesCtx *nodes = nullptr, const NgCtx *ng = nullptr) {
   // pending != NULL: the split reduction of the 256 x 256 weight-gradient tiles is NOT launched; its arguments go to
   // *pending for the caller to run (cinema_affine_trilerp_bwd_sorted_pending: beside the K1 coordinate gradient)
   if (pending) { pending->g.nprob = 0; pending->slab = nullptr; }
@@ -1062,10 +1081,40 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
       if (int rc = nodes_backward_chain(d, packed, coords_t, nodes->wrows, nodes->tiles, nodes->U, nodes->S, saved, dout, N, Npad,
                                         gbuf, gp, dcoords, wgrads, nodes->round_s, s, d16, dbf))
         return rc;
-    } else if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, d16, dbf))
+    } else if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, d16, dbf,
+                                             /*lat_bias=*/ng == nullptr))
       return rc;
     dout_prep_done = prep_rides;
   }
+  // ---- node-space reductions of ds / dt / dOut (replace the d-latent GEMM, the linear_lats weight-gradient problems on
+  //      sample rows and the K1 backward's per-sample passes) ----
+  NgPlan ngp = {};
+  if (ng != nullptr) {
+    CINEMA_REQUIRE(fused_chain, "node gradients need the activation-stationary bf16 chain kernels");
+    ngp = ng_plan(d, ng->S, Npad);
+    if (phases & CINEMA_BWD_PHASE_CHAIN) {
+      if (!dout_prep_done) {     // frozen weights: the dOut16 rows are still an operand of the node reduction
+        FinalBwdArgs a = {};
+        a.dout = dout; a.out_dim = d->out_dim; a.dbf = nullptr; a.Npad = (int)Npad;
+        const int grid_f = (int)std::min<int64_t>((Npad + WG_THREADS - 1) / WG_THREADS, 256);
+        hipLaunchKernelGGL((k_dout_prep<T>), dim3(grid_f), dim3(WG_THREADS), 0, s, a, gb + slot * (d->n_gbuf - 1));
+        CINEMA_CHECK_HIP(hipGetLastError());
+        dout_prep_done = wgrads;   // (its bias gradient was not taken: a weight-gradient pass would have to redo it)
+      }
+      if (int rc = ng_launch_grad(d, ngp, ng->work, gbuf, coords_t, ng->idx, N, ng->lx, ng->ly, ng->lz, s)) return rc;
+    }
+  }
+  auto ng_tail = [&](const Dw256Args *red, bool weights_side, bool table_side) -> int {
+    NgTailArgsHost t = {};
+    t.reduce = red;
+    if (weights_side && wgrads) t.grad_params = gp;
+    if (table_side) {
+      t.dlatents = ng->dlatents; t.dcond = ng->dcond; t.dembed = ng->dembed; t.embed = ng->embed; t.tf_dim = ng->tf_dim;
+      t.coords = ng->coords; t.dcoords = dcoords; t.idx = ng->idx;
+    }
+    t.N = N; t.C = ng->C; t.G = ng->lx * ng->ly * ng->lz; t.cond_dims = ng->cond_dims;
+    return ng_launch_tail(d, ngp, ng->work, t, s);
+  };
   for (int i = nl - 1; i >= 0 && (phases & CINEMA_BWD_PHASE_CHAIN) && !fused_chain; --i) {
     const bool mod = (d->modulated_mask >> i) & 1u;
     const bool top = i == nl - 1, first = i == 0;
@@ -1109,7 +1158,31 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   }
 
   // ---- d lat ----
-  if (phases & CINEMA_BWD_PHASE_DLAT) {
+  if (ng != nullptr && (phases & CINEMA_BWD_PHASE_DLAT)) {
+    // d (node rows) = sum_j (dU_s Wl_scale + dU_t Wl_shift) + dUo Wf[:, H:]  on S*32 node rows, one part per segment
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      DlatArgs a = {};
+      const bf16_t *dU = (const bf16_t *)((const char *)ng->work + ngp.dU);
+      int ns = 0;
+      for (int j = 0; j < ngp.n_mod; ++j) {
+        const int i = ngp.layer_of[j];
+        a.seg[ns].A = pk + d->pk_wlsT[i]; a.seg[ns].B = dU + (size_t)j * 2 * HP; a.seg[ns].K = HP; ++ns;
+        a.seg[ns].A = pk + d->pk_wltT[i]; a.seg[ns].B = dU + (size_t)j * 2 * HP + HP; a.seg[ns].K = HP; ++ns;
+      }
+      a.nseg = ns;
+      a.Xs = (const float *)((const char *)ng->work + ngp.dUo32); a.ldxs = 16; a.ks = d->out_dim;
+      a.Ws = params + d->off_wf + H; a.ws_sf = 1; a.ws_sk = H + L;
+      a.lat = L; a.LP = LP; a.ldg = ngp.F; a.out = (float *)((char *)ng->work + ngp.dT);
+      a.seg_split = 1; a.part_stride = ngp.Rp * (long)LP;
+      a.tiles_f = (LP + 127) / 128;
+      const int g2 = a.tiles_f * (int)(ngp.Rp / 128) * ns;
+      constexpr int smem = Engine<T>::NT_SMEM;
+      CINEMA_SMEM_ATTR(k_dlat<T>, smem);
+      hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
+      CINEMA_CHECK_HIP(hipGetLastError());
+    }
+    if (!wgrads || dlat_only) return ng_tail(nullptr, false, true);
+  } else if (phases & CINEMA_BWD_PHASE_DLAT) {
     DlatArgs a = {};
     int ns = 0;
     for (int i = 0; i < nl; ++i)
@@ -1141,6 +1214,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     }
   }
   if (!wgrads) return 0;
+  if (ng != nullptr && dlat_only) return 0;
 
   // ---- final_linear: dOut -> [Npad x 16] T copy (operand of the grouped launch) + bias gradient ----
   T *dout16 = gb + slot * (d->n_gbuf - 1);
@@ -1155,23 +1229,38 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
   if (phases & CINEMA_BWD_PHASE_DW) {
     DwArgs a = {};
     int np = 0, tiles = 0;
-    auto add = [&](const void *P, const void *Q, float *out, int ldp, int ldq, int ldo, int M, int K) {
-      DwProb p = {P, Q, out, ldp, ldq, ldo, M, K, (K + 127) / 128};
+    auto add = [&](const void *P, const void *Q, float *out, int ldp, int ldq, int ldo, int M, int K, int rows = 0) {
+      DwProb p = {P, Q, out, ldp, ldq, ldo, M, K, (K + 127) / 128, rows ? rows : (int)Npad};
       a.p[np] = p;
       a.tile_start[np] = tiles;
       tiles += ((M + 127) / 128) * p.tk;
       ++np;
     };
+    // node gradients: the linear_lats (and final_linear latent-column) problems reduce over the S*32 node rows
+    // (P = dU, Q = node rows of the table) instead of the N sample rows (P = ds / dt, Q = lat)
+    const T *ngT = ng ? (const T *)((const char *)ng->work + ngp.T) : nullptr;
+    const T *ngU = ng ? (const T *)((const char *)ng->work + ngp.dU) : nullptr;
+    const int ngF = ngp.F, ngR = (int)ngp.Rp;
+    int jm = ngp.n_mod;
     for (int i = nl - 1; i >= 0; --i) {
       if (i > 0) add(gb + slot * d->gb_z[i], sv + slot * d->sv_y[i - 1], gp + d->off_w[i], HP, HP, H, H, H);
       if ((d->modulated_mask >> i) & 1u) {
-        add(gb + slot * d->gb_s[i], lat, gp + d->off_wl[i], HP, LP, L, H, L);
-        add(gb + slot * d->gb_t[i], lat, gp + d->off_wl[i] + (size_t)H * L, HP, LP, L, H, L);
+        if (ng != nullptr) {
+          --jm;
+          add(ngU + (size_t)jm * 2 * HP, ngT, gp + d->off_wl[i], ngF, LP, L, H, L, ngR);
+          add(ngU + (size_t)jm * 2 * HP + HP, ngT, gp + d->off_wl[i] + (size_t)H * L, ngF, LP, L, H, L, ngR);
+        } else {
+          add(gb + slot * d->gb_s[i], lat, gp + d->off_wl[i], HP, LP, L, H, L);
+          add(gb + slot * d->gb_t[i], lat, gp + d->off_wl[i] + (size_t)H * L, HP, LP, L, H, L);
+        }
       }
     }
     // final_linear.weight [out x (H + L)]: columns [0,H) against x_L, columns [H,H+L) against lat
     add(dout16, sv + slot * d->sv_y[nl - 1], gp + d->off_wf, 16, HP, H + L, d->out_dim, H);
-    add(dout16, lat, gp + d->off_wf + H, 16, LP, H + L, d->out_dim, L);
+    if (ng != nullptr)
+      add((const T *)((const char *)ng->work + ngp.dUo16), ngT, gp + d->off_wf + H, 16, LP, H + L, d->out_dim, L, ngR);
+    else
+      add(dout16, lat, gp + d->off_wf + H, 16, LP, H + L, d->out_dim, L);
     a.tile_start[np] = tiles;
     a.nprob = np;
     a.Npad = (int)Npad;
@@ -1179,27 +1268,38 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
       if (d->gb_extra_bytes > 0 && Npad >= 4096) {
         // 256 x 256 tiles, one workgroup per CU; partial tiles go to the slab region behind the gbuf tensors
         Dw256Args b = {};
-        int t256 = 0;
+        int t256 = 0, t_main = 0, t_node = 0;
         for (int q = 0; q < np; ++q) {
           b.g.p[q] = a.p[q];
           b.g.p[q].tk = (a.p[q].K + 255) / 256;
           b.g.tile_start[q] = t256;
-          t256 += ((a.p[q].M + 255) / 256) * b.g.p[q].tk;
+          const int tq = ((a.p[q].M + 255) / 256) * b.g.p[q].tk;
+          t256 += tq;
+          (a.p[q].rows == (int)Npad ? t_main : t_node) += tq;
         }
         b.g.tile_start[np] = t256;
         b.g.nprob = np;
         b.g.Npad = (int)Npad;
+        // one workgroup per CU: the problems over the sample rows are split, the (12 x shorter) ones over node rows are not
         const int ncu = cinema_cu_count();
-        int sk = std::max(1, std::min(DW256_MAX_SPLIT, ncu / std::max(t256, 1)));
+        int sk = std::max(1, std::min(DW256_MAX_SPLIT, (ncu - t_node) / std::max(t_main, 1)));
         sk = std::min(sk, std::max(1, (int)(Npad / DW256_BN) / 4));
         b.g.splitk = sk;
-        CINEMA_REQUIRE((int64_t)t256 * DW256_MAX_SPLIT * 256 * 256 * 4 + 256 <= d->gb_extra_bytes,
+        int nwg = 0;
+        for (int q = 0; q < np; ++q) {
+          DwProb &pq = b.g.p[q];
+          pq.nsplit = pq.rows == (int)Npad ? sk : 1;
+          pq.wg0 = nwg; pq.slab0 = nwg;
+          nwg += (b.g.tile_start[q + 1] - b.g.tile_start[q]) * pq.nsplit;
+        }
+        CINEMA_REQUIRE((int64_t)nwg * 256 * 256 * 4 + 256 <= d->gb_extra_bytes,
                        "cinema_siren_backward: gb_extra_bytes of the descriptor is smaller than the plan's");
         const size_t gb_bytes = ((size_t)d->n_gbuf * Npad * HP * sizeof(T) + 255) / 256 * 256;
         b.slab = (float *)((char *)gbuf + gb_bytes);
         CINEMA_SMEM_ATTR(k_dw256, DW256_SMEM);
-        hipLaunchKernelGGL(k_dw256, dim3(t256 * sk), dim3(DW256_THREADS), DW256_SMEM, s, b);
+        hipLaunchKernelGGL(k_dw256, dim3(nwg), dim3(DW256_THREADS), DW256_SMEM, s, b);
         CINEMA_CHECK_HIP(hipGetLastError());
+        if (ng != nullptr) return ng_tail(&b, true, !weights_first);
         if (pending) {
           *pending = b;
         } else {
@@ -1218,6 +1318,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
     CINEMA_SMEM_ATTR(k_dw_grouped<T>, smem);
     hipLaunchKernelGGL((k_dw_grouped<T>), dim3(tiles * splitk), dim3(WG_THREADS), smem, s, a);
     CINEMA_CHECK_HIP(hipGetLastError());
+    if (ng != nullptr) return ng_tail(nullptr, true, !weights_first);
   }
   (void)N;
   return 0;
@@ -1254,6 +1355,32 @@ extern "C" int cinema_siren_backward_deferred(const cinema_siren_desc *d, const 
                                      dcoords, flags, s, (Dw256Args *)pending)
              : backward_impl<float>(d, params, packed, coords_t, lat, saved, dout, N, Npad, gbuf, grad_params, dlat,
                                     dcoords, flags, s, (Dw256Args *)pending);
+}
+
+// ----------------------------------------------------------------------------------------
+// backward with the latent side reduced in node space (nodegrad.h): SIREN backward + K1 backward in one call
+// ----------------------------------------------------------------------------------------
+extern "C" int cinema_siren_backward_nodegrad(const cinema_siren_desc *d, const float *params, const void *packed,
+                                              const float *coords_t, const void *saved, const float *dout, int64_t N,
+                                              int64_t Npad, void *gbuf, float *grad_params, float *dcoords, int32_t flags,
+                                              const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,
+                                              int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
+                                              void *work, float *dlatents, float *dembed, float *dcond, void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && saved && dout && gbuf && dcoords && coords && idx && work && dlatents,
+                 "cinema_siren_backward_nodegrad: null argument");
+  CINEMA_REQUIRE(ng_eligible(d, lx, ly, lz) && fused_mode(d) == 64,
+                 "cinema_siren_backward_nodegrad: needs a bf16 stack on the activation-stationary path (hidden <= 512) with a "
+                 "modulated layer and a latent grid of at most %d nodes", NG_ONE_SLOT - 1);
+  CINEMA_REQUIRE((flags & CINEMA_BWD_SKIP_WEIGHT_GRADS) || grad_params, "cinema_siren_backward_nodegrad: grad_params is null");
+  CINEMA_REQUIRE(!(flags & CINEMA_BWD_PHASE_MASK), "cinema_siren_backward_nodegrad: no phase selection on this entry point");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0 && S >= 1, "cinema_siren_backward_nodegrad: need 1 <= N <= Npad, Npad %% 128 == 0, S >= 1");
+  CINEMA_REQUIRE(C >= 1 && C + cond_dims == d->lat, "cinema_siren_backward_nodegrad: C + cond_dims = %d != lat_size %d", C + cond_dims, d->lat);
+  CINEMA_REQUIRE(dembed == nullptr || (embed != nullptr && (tf_dim == 6 || tf_dim == 9 || tf_dim == 12)),
+                 "cinema_siren_backward_nodegrad: dembed needs the embedding table (width 6, 9 or 12)");
+  CINEMA_REQUIRE(dcond == nullptr || cond_dims > 0, "cinema_siren_backward_nodegrad: dcond without condition columns");
+  const NgCtx ng = {work, coords, idx, embed, tf_dim, S, C, lx, ly, lz, cond_dims, dlatents, dembed, dcond};
+  return backward_impl<bf16_t>(d, params, packed, coords_t, nullptr, saved, dout, N, Npad, gbuf, grad_params, nullptr, dcoords,
+                               flags, (hipStream_t)stream, nullptr, nullptr, &ng);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -28,40 +28,6 @@ __global__ void k_affine_from_embed(const float *embed, long rows, int dim, floa
   o[9] = e[3]; o[10] = e[4]; o[11] = e[5];
 }
 
-// d embed from d coords_t:  coords_t = A c + t
-// gradient of the loss w.r.t. one embedding row e from G = dL/dA (3x3) and d = dL/dt: every component is LINEAR in
-// (G, d), so a subject's table row needs only the sums of d c^T and d over its samples (k_tf_table_bwd)
-__device__ __forceinline__ void embed_grad(const float (&e)[12], int dim, const M3 &G, const float (&d)[3], float (&g)[12]) {
-  float s1, c1, s2, c2, s3, c3;
-  sincosf(e[0], &s1, &c1);
-  sincosf(e[1], &s2, &c2);
-  sincosf(e[2], &s3, &c3);
-  const M3 Rz1 = rot_z(c1, s1), Rx2 = rot_x(c2, s2), Rz3 = rot_z(c3, s3);
-  const M3 R = m3_mul(m3_mul(Rz1, Rx2), Rz3);
-  M3 D = m3_identity(), Sh = m3_identity(), sx = m3_identity(), sy = m3_identity(), sz = m3_identity();
-  if (dim >= 9) { D.m[0][0] = 1.f + e[6]; D.m[1][1] = 1.f + e[7]; D.m[2][2] = 1.f + e[8]; }
-  if (dim == 12) { shear_mats(e, sx, sy, sz); Sh = m3_mul(m3_mul(sx, sy), sz); }
-  // rotation angles: <G (D Sh)^T, dR/dtheta>
-  const M3 GR = m3_mul(G, m3_t(m3_mul(D, Sh)));
-  g[0] = m3_dot(GR, m3_mul(m3_mul(drot_z(c1, s1), Rx2), Rz3));
-  g[1] = m3_dot(GR, m3_mul(m3_mul(Rz1, drot_x(c2, s2)), Rz3));
-  g[2] = m3_dot(GR, m3_mul(m3_mul(Rz1, Rx2), drot_z(c3, s3)));
-  g[3] = d[0]; g[4] = d[1]; g[5] = d[2];
-  if (dim >= 9) {
-    const M3 GD = m3_mul(m3_mul(m3_t(R), G), m3_t(Sh));
-    g[6] = GD.m[0][0]; g[7] = GD.m[1][1]; g[8] = GD.m[2][2];
-  }
-  if (dim == 12) {
-    const M3 GS = m3_mul(m3_t(m3_mul(R, D)), G);                 // dL/dSh
-    const M3 gsx = m3_mul(GS, m3_t(m3_mul(sy, sz)));
-    const M3 gsy = m3_mul(m3_mul(m3_t(sx), GS), m3_t(sz));
-    const M3 gsz = m3_mul(m3_t(m3_mul(sx, sy)), GS);
-    g[9] = gsy.m[1][0] + gsz.m[2][0];
-    g[10] = gsx.m[0][1] + gsz.m[2][1];
-    g[11] = gsx.m[0][2] + gsy.m[1][2];
-  }
-}
-
 __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const float *embed, int dim, int per_sample,
                              const float *dct, long N, long S, float *dembed) {
   const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -212,6 +212,73 @@ class SirenEngine:
               "cinema_siren_backward")
 
 
+    def backward_nodegrad(self, n: int, dout_padded: torch.Tensor, ng: "NodeGrad", coords: torch.Tensor, idx: torch.Tensor,
+                          tfs: Optional[torch.Tensor], latents_shape, cond_dims: int, dlatents: torch.Tensor,
+                          dtfs: Optional[torch.Tensor], dcond: Optional[torch.Tensor], weight_grads: bool = True,
+                          dcoords_cleared: bool = False, part: int = 0):
+        """SIREN backward + K1 backward in one call with the latent side reduced in node space (include/cinema_hip.h,
+        "node gradients"): fills flat_grad, dlatents (S, C, lx, ly, lz), dtfs (S, tf_dim), dcond (S, cond_dims).
+        The batch must be grouped by subject and nodegrad_prepare must have run on the current parameters."""
+        ws = self.ws
+        ws.ensure_backward()
+        npad = round_up(n, ROW_ALIGN)
+        S, Cc, lx, ly, lz = latents_shape
+        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | part
+        if dcoords_cleared:
+            flags |= _lib.BWD_DCOORDS_CLEARED
+        if weight_grads and part != _lib.BWD_DLAT_ONLY:
+            if self.grads_clean:
+                flags |= _lib.BWD_GRADS_CLEARED
+            self.grads_clean = False
+        check(self.lib.cinema_siren_backward_nodegrad(
+            C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t), ptr(ws.saved), ptr(dout_padded), n, npad,
+            ptr(ws.gbuf), ptr(self.flat_grad), ptr(ws.dcoords), flags, ptr(coords), ptr(idx), ptr(tfs),
+            0 if tfs is None else tfs.shape[1], S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), ptr(dlatents),
+            ptr(dtfs) if tfs is not None else None, ptr(dcond), self.stream()), "cinema_siren_backward_nodegrad")
+
+
+class NodeGrad:
+    """Work buffer of the node-space backward for one (subject count, batch size)."""
+
+    def __init__(self):
+        self.work = None
+        self._bufs = {}     # (S, Npad) -> buffer: the layout depends on both, and its pad rows must stay zero
+
+    def ensure(self, eng: "SirenEngine", S: int, npad: int):
+        buf = self._bufs.get((S, npad))
+        if buf is None:
+            nbytes = eng.lib.cinema_nodegrad_work_bytes(C.byref(eng.desc), S, npad)
+            if nbytes < 0:
+                check(-1, "cinema_nodegrad_work_bytes")
+            if len(self._bufs) >= 2:      # a step-sized batch and the epoch's short last chunk
+                self._bufs.clear()
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=eng.device)
+            self._bufs[(S, npad)] = buf
+        self.work = buf
+
+
+def nodegrad_eligible(eng: "SirenEngine", latents_shape) -> bool:
+    """Shapes the node-space backward takes (bf16 activation-stationary stack with a modulated layer, at most 30 grid
+    nodes); CINEMA_NODE_GRAD=0 keeps the per-sample backward (A/B switch)."""
+    _, _, lx, ly, lz = latents_shape
+    return (os.environ.get("CINEMA_NODE_GRAD", "1") != "0" and eng.can_skip_saved()
+            and eng.lib.cinema_nodegrad_eligible(C.byref(eng.desc), lx, ly, lz) == 1)
+
+
+def nodegrad_prepare(eng: "SirenEngine", ng: NodeGrad, coords: torch.Tensor, idx: torch.Tensor, table: torch.Tensor,
+                     cond_subject: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
+    """Interpolation weights of the batch + node rows / centred node projections of the current table (after the packed
+    weight copies were refreshed: step_head, or eng.pack(2 | 8))."""
+    S, Cc, lx, ly, lz = table.shape
+    cond_dims = 0 if cond_subject is None else cond_subject.shape[1]
+    npad = round_up(n, ROW_ALIGN)
+    ng.ensure(eng, S, npad)
+    check(eng.lib.cinema_nodegrad_prepare(C.byref(eng.desc), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
+                                          0 if tfs is None else tfs.shape[1], ptr(table), ptr(cond_subject) if cond_dims else None,
+                                          n, npad, S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), eng.stream()),
+          "cinema_nodegrad_prepare")
+
+
 class NodeTables:
     """Buffers of the nodes path for one latent table (include/cinema_hip.h, "Nodes" section): node rows T, their
     projections U / V, and the per-sample weight rows of the current batch."""

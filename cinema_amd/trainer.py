@@ -173,6 +173,7 @@ class HotPathTrainer:
         self.ev_prep = torch.cuda.Event()
         self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
         self.nodes = E.NodeTables()                                    # node-space tables of the nodes path
+        self.ng = E.NodeGrad()                                         # work buffer of the node-space backward
         self.n_last = 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
@@ -203,6 +204,9 @@ class HotPathTrainer:
         use_nodes = grouped and self.conv is None and E.nodes_eligible(eng, tuple(self.latents.shape))
         if use_nodes:
             return self._step_nodes(lo, hi)
+        # node gradients: the latent side of the backward (d table, d linear_lats, d coords through the interpolation)
+        # reduced in node space -- one call instead of SIREN backward + K1 backward
+        use_ng = grouped and E.nodegrad_eligible(eng, tuple(table.shape))
 
         def k1_fwd():
             if fast_k1:
@@ -211,8 +215,8 @@ class HotPathTrainer:
                 E.k1_forward(eng, self.k1, coords, subj, table, cond, tfs, False, n)
 
         def backward_only_prep():
-            eng.pack(2)                                           # transposed linear_lats copies,
-            if fast_k1:
+            eng.pack(2 | (8 if use_ng else 0))                    # transposed (and row-major) linear_lats copies,
+            if fast_k1 and not use_ng:
                 E.k1_shadow(eng, self.k1, table)                  # node-major shadow (only the K1 backward reads it),
             E.step_prepare(ws.dcoords, self.sums, n, self.n_cls, self.class_w if use_cw else None, voxel, subj, st.labels, st.V,
                            self.prep_scratch)                     # cleared sums / dcoords + class-weight normaliser
@@ -222,7 +226,7 @@ class HotPathTrainer:
             # everything in front of the forward as ONE launch (cinema_step_head): no second stream, no join
             E.step_head(eng, self.k1, coords, subj, table, cond_table, tfs, n, cond_by_subject=True,
                         prepare=dict(dcoords=ws.dcoords, sums=self.sums, n_cls=self.n_cls, class_w=self.class_w if use_cw else None,
-                                     voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch))
+                                     voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch), shadow=not use_ng)
         elif self.side is not None:
             side = self.side
             side.wait_stream(main)                  # the previous step's optimiser wrote the parameters
@@ -240,6 +244,8 @@ class HotPathTrainer:
         eng.forward(n)
         if not joined:
             main.wait_event(self.ev_prep)
+        if use_ng:
+            E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
                       labels=st.labels, voxels_per_subject=st.V, prepared=True, norm=None if norm is None else norm.wait())
@@ -247,7 +253,20 @@ class HotPathTrainer:
         # tiles rides with the K1 backward's first launch (beside the coordinate gradient) instead of a launch of its own
         pending = self.pending if (grouped and self.train_mlp and self.world == 1) else None
         work = None
-        if self.train_mlp and self.world > 1:
+        want_tf = self.tfs.requires_grad
+        if use_ng:
+            if self.cond_param is not None and self.cond_grad is None:
+                self.cond_grad = torch.zeros_like(self.cond_param)
+            ng_args = dict(ng=self.ng, coords=coords, idx=subj, tfs=tfs, latents_shape=tuple(table.shape), cond_dims=self.cond_dims,
+                           dlatents=self.lat_grad if self.conv is None else self.table_grad, dtfs=self.tf_grad if want_tf else None,
+                           dcond=self.cond_grad if self.cond_param is not None else None)
+            if self.train_mlp and self.world > 1:
+                eng.backward_nodegrad(n, ws.dout, weight_grads=True, dcoords_cleared=True, part=_lib.BWD_WEIGHTS_FIRST, **ng_args)
+                work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+                eng.backward_nodegrad(n, ws.dout, weight_grads=True, part=_lib.BWD_DLAT_ONLY, **ng_args)
+            else:
+                eng.backward_nodegrad(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, **ng_args)
+        elif self.train_mlp and self.world > 1:
             # rank of several: weight gradients first, their all-reduce starts at once and runs beside the d-latent GEMM,
             # the K1 backward and the table-side AdamW
             eng.backward(n, ws.dout, weight_grads=True, dcoords_cleared=True, part=_lib.BWD_WEIGHTS_FIRST)
@@ -255,12 +274,13 @@ class HotPathTrainer:
             eng.backward(n, ws.dout, weight_grads=True, part=_lib.BWD_DLAT_ONLY)
         else:
             eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, pending=pending)
-        want_tf = self.tfs.requires_grad
-        _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
-                                    tfs if want_tf else None, False, n, want_latents=True,
-                                    want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
-                                    dlat_out=self.lat_grad if self.conv is None else self.table_grad, grouped=grouped,
-                                    pending=pending)
+        dcond = None
+        if not use_ng:
+            _, _, dcond = E.k1_backward(eng, self.k1, coords, subj, tuple(self.latents.shape), self.cond_dims,
+                                        tfs if want_tf else None, False, n, want_latents=True,
+                                        want_cond=self.cond_param is not None, dtf_out=self.tf_grad if want_tf else None,
+                                        dlat_out=self.lat_grad if self.conv is None else self.table_grad, grouped=grouped,
+                                        pending=pending)
         work_conv = []
         if self.conv is not None:
             self._latent_table_backward()
@@ -272,7 +292,7 @@ class HotPathTrainer:
         if want_tf:
             self.tfs.grad = self.tf_grad
         if self.cond_param is not None:
-            self.cond_param.grad = self._cond_table_grad(subj, dcond, n, grouped)
+            self.cond_param.grad = self.cond_grad if use_ng else self._cond_table_grad(subj, dcond, n, grouped)
         self.opt_local.step()
         for w in [work] + work_conv:
             if w is not None:

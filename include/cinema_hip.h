@@ -118,7 +118,8 @@ int cinema_siren_plan(cinema_siren_desc *d /* host */);
 int cinema_siren_pack(const cinema_siren_desc *d /* host */, const float *params, void *packed, void *stream);
 /* The same in parts (a mask) for a training loop that packs beside other work: 1 = the copies the forward reads,
  * 2 = the copies only the backward reads (the forward can start after part 1), 4 = the copies of the nodes path
- * (forward stream without linear_lats segments, row-major linear_lats for cinema_node_tables). */
+ * (forward stream without linear_lats segments, row-major linear_lats for cinema_node_tables), 8 = row-major linear_lats
+ * only (cinema_nodegrad_prepare). */
 int cinema_siren_pack_part(const cinema_siren_desc *d /* host */, const float *params, void *packed, int32_t part,
                            void *stream);
 
@@ -329,6 +330,41 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
                                 int64_t S, const void *saved, const float *dout, int64_t N, int64_t Npad, void *gbuf,
                                 float *grad_params, float *dlat, float *dcoords, int32_t flags, void *pending /* host, may be NULL */,
                                 void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * Backward with the latent side reduced in NODE space ("node gradients"; bf16 chain kernels, hidden <= 512, at most 30
+ * grid nodes, batch grouped by subject: idx non-decreasing -- the caller's precondition, not checked).
+ * What autograd does for models/inr_decoder.py:64-85 + models/siren.py:26-36,59-61 in ONE call: it replaces
+ * cinema_siren_backward + cinema_affine_trilerp_bwd_sorted for a training loop.  The interpolated latent of a sample is a
+ * convex combination of its subject's grid nodes and linear_lats / the latent columns of final_linear are linear, so the
+ * per-sample rows X[n] = [ds_j | dt_j]_j, dOut that leave the chain kernels are reduced ONCE to
+ *   dU[s][k] = sum_{n of s} w[n][k] X[n]   (k: the subject's 27 nodes + a constant-1 slot)   and
+ *   dwn[n][k] = X[n] . linear_lats(table[s][k] - mean_k table[s][k]),
+ * after which d linear_lats.weight / .bias, d final_linear.weight[:, H:] and d table are GEMMs over S*32 node rows
+ * instead of N sample rows and  d coords[n] += sum_k dwn[n][k] d w[n][k] / d coords  (no per-sample d-latent rows,
+ * no per-sample latent reduction).  Same function as the per-sample calls; different rounding (bf16 interpolation
+ * weights and node sums).
+ *   work: cinema_nodegrad_work_bytes(d, S, Npad) bytes of device memory, zeroed once by the caller.
+ *   cinema_nodegrad_prepare: per step, after the weights were packed (cinema_siren_pack_part with bits 2 | 8, or
+ *     cinema_step_head) -- interpolation weights of the batch, node rows and centred node projections of the current
+ *     table (`latents` (S, C, lx, ly, lz): the table K1 interpolates; cond_subject [S x cond_dims] or NULL).
+ *   cinema_siren_backward_nodegrad: flags as cinema_siren_backward (SKIP_WEIGHT_GRADS, GRADS_CLEARED, DCOORDS_CLEARED,
+ *     WEIGHTS_FIRST / DLAT_ONLY: the first call leaves grad_params complete, the second one the table-side gradients).
+ *     Outputs (overwritten): grad_params, dlatents (S, C, lx, ly, lz), dembed [S x tf_dim] or NULL, dcond [S x cond_dims]
+ *     or NULL (per-SUBJECT condition gradient).  dcoords [Npad x 3] holds the first layer's part only.
+ * ------------------------------------------------------------------------------------- */
+int cinema_nodegrad_eligible(const cinema_siren_desc *d /* host */, int32_t lx, int32_t ly, int32_t lz);
+int64_t cinema_nodegrad_work_bytes(const cinema_siren_desc *d /* host */, int64_t S, int64_t Npad);
+int cinema_nodegrad_prepare(const cinema_siren_desc *d /* host */, const void *packed, const float *coords, const int32_t *idx,
+                            const float *embed, int32_t tf_dim, const float *latents, const float *cond_subject, int64_t N,
+                            int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
+                            void *work, void *stream);
+int cinema_siren_backward_nodegrad(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                                   const float *coords_t, const void *saved, const float *dout, int64_t N, int64_t Npad,
+                                   void *gbuf, float *grad_params, float *dcoords, int32_t flags, const float *coords,
+                                   const int32_t *idx, const float *embed, int32_t tf_dim, int64_t S, int32_t C, int32_t lx,
+                                   int32_t ly, int32_t lz, int32_t cond_dims, void *work, float *dlatents, float *dembed,
+                                   float *dcond, void *stream);
 
 /* -------------------------------------------------------------------------------------
  * K3: ground-truth sampling + loss + dLoss/dOutput (Criterion.forward, utils.py:88-104,

@@ -1,0 +1,77 @@
+"""GPU tests of the node-space backward (include/cinema_hip.h, "node gradients"): the same trainer step with the latent
+side of the backward reduced over S*32 node rows (default) and over the N sample rows (CINEMA_NODE_GRAD=0: SIREN backward
++ K1 backward), on the same parameters and samples.  Both are the same function in different rounding; the oracle
+comparisons of tests/test_gpu_trainer.py run on the default."""
+import pytest
+import torch
+
+from conftest import both_errs, failing
+from test_gpu_trainer import DEV, base_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _one_step(monkeypatch, node_grad, args, store, n, split="train", cond_seed=None):
+    from cinema_amd.trainer import HotPathTrainer
+    from cinema_amd import engine as E
+    monkeypatch.setenv("CINEMA_NODE_GRAD", "1" if node_grad else "0")
+    torch.manual_seed(21)
+    tr = HotPathTrainer(args, store, DEV, keep_grads=True, split=split)
+    with torch.no_grad():
+        tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+        # make the modulation (and with it the latent-side gradients) matter
+        for k, v in tr.eng.param_views().items():
+            if "linear_lats.weight" in k:
+                v.mul_(3.0)
+    assert E.nodegrad_eligible(tr.eng, tuple(tr.latents.shape)) == node_grad
+    tr.step(0, n)
+    torch.cuda.synchronize()
+    out = {"glat": tr.lat_grad.clone(), "gtf": tr.tf_grad.clone(), "gflat": tr.eng.flat_grad.clone()}
+    if tr.cond_param is not None:
+        out["gcond"] = tr.cond_param.grad.clone()
+    views = tr.eng.param_views(tr.eng.flat_grad.clone())
+    return out, views
+
+
+@pytest.mark.parametrize("shape", ["small", "ragged", "bench"])
+def test_node_gradients_equal_per_sample_backward(shape, monkeypatch):
+    from cinema_amd.trainer import SubjectStore
+    if shape == "bench":
+        S, side, latent_dim, hidden, layers, mod, n = 64, 28, [256, 3, 3, 3], 512, 5, [1, 3, 5], 25000
+    elif shape == "small":
+        S, side, latent_dim, hidden, layers, mod, n = 5, 24, [48, 3, 3, 3], 128, 3, [1, 3], 700
+    else:       # a step that is not a multiple of anything, subjects of very different sizes, layer 0 modulated
+        S, side, latent_dim, hidden, layers, mod, n = 7, 20, [32, 3, 3, 3], 192, 2, [0, 2], 1003
+    args = base_args(latent_dim, hidden, layers, mod, [2, 10], 0, "bf16")
+    store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 2, 10, seed=7, device=DEV)
+    if shape == "ragged":       # drop most samples of two subjects and every sample of another one
+        keep = ~(((store.subj == 1) | (store.subj == 4)) & (torch.arange(len(store), device=DEV) % 37 != 0)) & (store.subj != 2)
+        store.coords, store.voxel, store.subj = store.coords[keep], store.voxel[keep], store.subj[keep]
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n)
+    ref, ref_v = _one_step(monkeypatch, False, args, store, n)
+    got, got_v = _one_step(monkeypatch, True, args, store, n)
+    errs = {}
+    for k in ("glat", "gtf"):
+        errs.update(both_errs(k, got[k].cpu().numpy(), ref[k].cpu().numpy()))
+    for k in ref_v:
+        errs.update(both_errs("g_" + k, got_v[k].cpu().numpy(), ref_v[k].cpu().numpy()))
+    bad = failing(errs, 1e-2, 6e-3)
+    assert not bad, bad
+
+
+def test_node_gradients_validation_split_with_conditions(monkeypatch):
+    """split='val' (frozen MLP, learnable per-subject conditions, lat = C + 1): table, embedding and condition gradients."""
+    from cinema_amd.trainer import SubjectStore
+    S, side, n = 6, 20, 900
+    args = base_args([63, 3, 3, 3], 128, 3, [1, 3], [1, 10], 1, "bf16")
+    store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 1, 10, seed=9, device=DEV, cond_dims=1,
+                                   cond_scale=0.12)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n)
+    ref, _ = _one_step(monkeypatch, False, args, store, n, split="val")
+    got, _ = _one_step(monkeypatch, True, args, store, n, split="val")
+    errs = {}
+    for k in ("glat", "gtf", "gcond"):
+        errs.update(both_errs(k, got[k].cpu().numpy(), ref[k].cpu().numpy()))
+    assert float(got["gflat"].abs().max()) == 0.0
+    bad = failing(errs, 1e-2, 6e-3)
+    assert not bad, bad

@@ -463,7 +463,7 @@ def test_step_head_equals_the_separate_launches():
     sums_a, sums_b = torch.full((4,), 7.0, device=DEV), torch.full((4,), 7.0, device=DEV)
     scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=DEV)
     eng.packed.zero_()
-    eng.pack()
+    eng.pack(3 | 8)     # the head also leaves the row-major linear_lats copies of the node-space backward
     ws.coords_t.fill_(float("nan")); ws.lat.fill_(float("nan")); ws.dcoords.fill_(3.0)
     E.k1_forward_sorted(eng, coords, idx, latents, None, tfs, n)
     E.k1_shadow(eng, st_a, latents)
