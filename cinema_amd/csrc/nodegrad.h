@@ -12,12 +12,13 @@
 // over S*32 node rows instead of N sample rows, and d coords = sum_k dwn[n][k] * d w[n][k] / d coords.
 //
 // Work buffer (caller-owned, cinema_nodegrad_work_bytes; zeroed once by the caller, rows >= S*32 stay zero):
+//   offs   int32 [S + 1]            first row of every subject in the grouped batch
 //   wt     bf16 [Npad/16][32][16]   interpolation weights, per 16-row block, slot-major (MFMA operand order)
 //   T      bf16 [Rp][LP]            node rows of the table (+ the subject's conditions), Rp = S*32 rounded up to 128
 //   Up     bf16 [S*32][F]           centred projections U', F = n_mod * 2 * HP
 //   Vp     bf16 [S*32][16]          the same through final_linear.weight[:, H:]
 //   dU     bf16 [Rp][F], dUo16 bf16 [Rp][16], dUo32 fp32 [Rp][16]
-//   dcn    fp32 [2 n_mod + 1][Npad][4]   per-tensor parts of d coords through the interpolation weights
+//   dcn    fp32 [nparts][Npad][4]   per-(tensor, column group) parts of d coords through the interpolation weights
 //   dT     fp32 [2 n_mod][Rp][LP]   per-segment parts of d (node rows)
 #pragma once
 #include "common.h"
@@ -27,9 +28,9 @@
 
 struct NgPlan {
   long S, Npad, Rp;
-  int n_mod, F, nparts, HP, LP;
+  int n_mod, F, nparts, ncg, HP, LP;
   int layer_of[CINEMA_MAX_LAYERS];
-  size_t wt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
+  size_t offs, wt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
 };
 bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz);
 NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad);

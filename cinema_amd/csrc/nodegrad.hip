@@ -68,11 +68,16 @@ __device__ __forceinline__ int ng_lower(const int32_t *idx, long N, long key, lo
 // ----------------------------------------------------------------------------------------
 struct NgWeightArgs {
   const float *coords; const int32_t *idx; const float *embed; int tf_dim; long N, S; int lx, ly, lz; bf16_t *wt;
+  int32_t *offs; int nblk;       // the workgroup behind the nblk row blocks writes offs[0..S]: first row of every subject
 };
 __global__ __launch_bounds__(512) void k_ng_weights(NgWeightArgs a) {
   __shared__ float ct[16][4];
   const int tid = threadIdx.x;
   const long blk = blockIdx.x;
+  if (blk >= a.nblk) {
+    for (long t = tid; t <= a.S; t += 512) a.offs[t] = ng_lower(a.idx, a.N, t, a.S);
+    return;
+  }
   if (tid < 16) {
     const long n = blk * 16 + tid;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, ok = 0.f;
@@ -204,12 +209,12 @@ __global__ __launch_bounds__(256) void k_ng_project(NgProjArgs a) {
 // ----------------------------------------------------------------------------------------
 struct NgGradArgs {
   const bf16_t *gbuf; long slot_elems; int gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS], layer_of[CINEMA_MAX_LAYERS];
-  int n_mod, dout_slot;
-  const bf16_t *wt, *Up, *Vp; const float *coords_t; const int32_t *idx;
+  int n_mod, dout_slot, ncg;
+  const bf16_t *wt, *Up, *Vp; const float *coords_t; const int32_t *offs;
   long N, Npad, S; int HP, F, lx, ly, lz, in_dim;
   bf16_t *dU, *dUo16; float *dUo32, *dcn;
+  int dbg;      // developer ablations (cinema_debug_node_grad): 1 = no exchange / d coords, 2 = no dU products, 4 = no dwn products
 };
-#define NG_NKB 2      // 32-feature blocks per wave: HP <= 512
 
 __device__ __forceinline__ bf16x4 cvt4(const f32x4 &v) {
   bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -218,11 +223,14 @@ __device__ __forceinline__ bf16x4 cvt4(const f32x4 &v) {
 __device__ __forceinline__ f32x4 mfma16(const bf16x4 &a, const bf16x4 &b, const f32x4 &c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
 }
-// the 4 weights (rows 16b + 4g .. + 3) of slot 16 nt + i, zero for rows outside [beg, end)
-__device__ __forceinline__ bf16x4 ng_wfrag(const bf16_t *wt, long b, int nt, int i, int g, int beg, int end) {
-  bf16x4 w = *reinterpret_cast<const bf16x4 *>(wt + ((b * NG_SLOTS + 16 * nt + i) * 16 + 4 * g));
-  const int n0 = (int)(16 * b) + 4 * g;
-  if (n0 < beg || n0 + 4 > end) {
+// the 4 weights (rows 16b + 4g .. + 3) of slot 16 nt + i; ng_wmask zeroes the rows outside [beg, end) -- at the point of
+// USE: touching the value where it is loaded would make the load wait there and undo the prefetch
+__device__ __forceinline__ bf16x4 ng_wload(const bf16_t *wt, long b, int nt, int i, int g) {
+  return *reinterpret_cast<const bf16x4 *>(wt + ((b * NG_SLOTS + 16 * nt + i) * 16 + 4 * g));
+}
+__device__ __forceinline__ bf16x4 ng_wmask(bf16x4 w, long b, int g, int beg, int end) {
+  if (16 * b < beg || 16 * b + 16 > end) {          // workgroup-uniform: only a subject's first and last block
+    const int n0 = (int)(16 * b) + 4 * g;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n0 + r < beg || n0 + r >= end) w[r] = (bf16_t)0.f;
@@ -230,14 +238,32 @@ __device__ __forceinline__ bf16x4 ng_wfrag(const bf16_t *wt, long b, int nt, int
   return w;
 }
 
-__device__ __forceinline__ void ng_body_tensor(const NgGradArgs &a, const long s, const int t, float (*P)[64][8], float (*R)[16][4],
-                                               const int beg, const int end) {
+// One tensor t = (modulated layer, half) and one group cg of 8 x 32 columns: wave w owns the 32-column block 8 cg + w.
+// Loads run three row blocks ahead through a ring of four register sets with STATIC slots (a rotating copy would
+// make every load wait at the copy); one barrier per row block (P, R and the axis table are double-buffered, the last
+// sum of a block is taken one block later).  The interpolation axes of the block's 16 rows (3 per row: nodes, weights,
+// d u / d coordinate) are worked out once, by 48 lanes of wave 1, and shared through LDS.
+struct NgAxis { int nodes; float w0, w1, dmul; };      // nodes = i0 | i1 << 8
+__device__ __forceinline__ float ngx_w(const NgAxis &a, int i) {
+  const int i0 = a.nodes & 255, i1 = a.nodes >> 8;
+  return (i == i0 ? a.w0 : 0.f) + ((i == i1 && i1 != i0) ? a.w1 : 0.f);
+}
+__device__ __forceinline__ float ngx_d(const NgAxis &a, int i) {
+  const int i0 = a.nodes & 255, i1 = a.nodes >> 8;
+  return (((i == i1) ? 1.f : 0.f) - ((i == i0) ? 1.f : 0.f)) * a.dmul;
+}
+
+__device__ __forceinline__ void ng_body_tensor(const NgGradArgs &a, const long s, const int t, const int cg, const int part,
+                                               float (*P)[8][64][8], float (*R)[8][16][4], NgAxis (*AX)[16][4], const int beg,
+                                               const int end) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int jm = t >> 1, half = t & 1, layer = a.layer_of[jm];
   const bf16_t *X = a.gbuf + a.slot_elems * (half ? a.gb_t[layer] : a.gb_s[layer]);
   const int nkb = a.HP >> 5;
+  const bool kv = 8 * cg + wave < nkb;                       // wave-uniform: this wave's column block exists
+  const int kb = kv ? 8 * cg + wave : 0;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   bf16x8 sel[2];
 #pragma unroll
@@ -245,114 +271,108 @@ __device__ __forceinline__ void ng_body_tensor(const NgGradArgs &a, const long s
     sel[0][e] = (bf16_t)((8 * g + e == i) ? 1.f : 0.f);
     sel[1][e] = (bf16_t)((8 * g + e == 16 + i) ? 1.f : 0.f);
   }
-  int kb[NG_NKB]; bool kv[NG_NKB];
-  bf16x8 up[NG_NKB][2];
-  f32x4 dUa[NG_NKB][2][2];
+  bf16x8 up[2];
+  f32x4 dUa[2][2];
 #pragma unroll
-  for (int q = 0; q < NG_NKB; ++q) {
-    kb[q] = wave + 8 * q;
-    kv[q] = kb[q] < nkb;
-    if (!kv[q]) kb[q] = 0;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      up[q][mt] = *reinterpret_cast<const bf16x8 *>(a.Up + (s * NG_SLOTS + 16 * mt + i) * a.F + (long)t * a.HP + 32 * kb[q] + 8 * g);
-      dUa[q][0][mt] = zero4; dUa[q][1][mt] = zero4;
-    }
+  for (int mt = 0; mt < 2; ++mt) {
+    up[mt] = *reinterpret_cast<const bf16x8 *>(a.Up + (s * NG_SLOTS + 16 * mt + i) * a.F + (long)t * a.HP + 32 * kb + 8 * g);
+    dUa[0][mt] = zero4; dUa[1][mt] = zero4;
   }
   const long b0 = beg >> 4, b1 = ((long)end + 15) >> 4;
-  auto loadX = [&](long b, bf16x8 (&x)[NG_NKB]) {
+#ifndef NG_RING
+#define NG_RING 4
+#endif
+  bf16x8 xr[NG_RING];
+  bf16x4 wr[NG_RING][2];
+  float cr[NG_RING];                  // wave 1, lane (i, g < 3): coordinate column g of row i
+  const bool ax_lane = wave == 1 && g < 3;
+  auto load = [&](long b, bf16x8 &x, bf16x4 (&w)[2], float &c) {
     const long bb = b < b1 ? b : b1 - 1;
-    const bf16_t *row = X + (bb * 16 + i) * a.HP + 8 * g;
+    if (ax_lane) c = a.coords_t[(bb * 16 + i) * 3 + g];
+    x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(X + (bb * 16 + i) * a.HP + 32 * kb + 8 * g));
 #pragma unroll
-    for (int q = 0; q < NG_NKB; ++q) x[q] = *reinterpret_cast<const bf16x8 *>(row + 32 * kb[q]);
+    for (int nt = 0; nt < 2; ++nt) w[nt] = ng_wload(a.wt, bb, nt, i, g);
   };
-  auto loadW = [&](long b, bf16x4 (&w)[2]) {
-    const long bb = b < b1 ? b : b1 - 1;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) w[nt] = ng_wfrag(a.wt, bb, nt, i, g, beg, end);
-  };
-  auto loadC = [&](long b, float (&c)[3]) {
-    const long bb = b < b1 ? b : b1 - 1;
-    const float *cp = a.coords_t + (bb * 16 + i) * a.in_dim;
-    c[0] = cp[0]; c[1] = a.in_dim > 1 ? cp[1] : 0.f; c[2] = a.in_dim > 2 ? cp[2] : 0.f;
-  };
-  bf16x8 x0[NG_NKB], x1[NG_NKB], x2[NG_NKB];
-  bf16x4 w0[2], w1[2];
-  float c0[3], c1[3];
-  loadX(b0, x0); loadW(b0, w0); loadC(b0, c0);
-  loadX(b0 + 1, x1); loadW(b0 + 1, w1); loadC(b0 + 1, c1);
-  loadX(b0 + 2, x2);
-  // slot this lane finishes after the exchange: wave -> (slot tile, lane group), lane group q -> register
+  for (int q = 0; q < NG_RING - 1; ++q) load(b0 + q, xr[q], wr[q], cr[q]);
+  // the slot this lane finishes after the exchange: wave -> (slot tile, lane group), lane group g -> accumulator register
   const int my_slot = 16 * (wave >> 2) + 4 * (wave & 3) + g;
-  for (long b = b0; b < b1; ++b) {
-    bf16x8 x3[NG_NKB];
-    bf16x4 w2[2];
-    float c2[3];
-    loadW(b + 2, w2); loadC(b + 2, c2);
-    loadX(b + 3, x3);
-    f32x4 cb[2] = {zero4, zero4};
-#pragma unroll
-    for (int q = 0; q < NG_NKB; ++q) {
-      if (kv[q]) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) cb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(up[q][mt], x0[q], cb[mt], 0, 0, 0);
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-          const bf16x4 xt = cvt4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(x0[q], sel[ft], zero4, 0, 0, 0));
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) dUa[q][ft][nt] = mfma16(xt, w0[nt], dUa[q][ft][nt]);
-        }
-      }
-    }
-    {
-      f32x4 *pp = reinterpret_cast<f32x4 *>(&P[wave][lane][0]);
-      pp[0] = cb[0]; pp[1] = cb[1];
-    }
-    __syncthreads();
-    {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) v += P[w][(wave & 3) * 16 + i][(wave >> 2) * 4 + g];
-      float jc[3];
-      slot_jacobian(c0[0], c0[1], c0[2], a.lx, a.ly, a.lz, my_slot, jc);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float p = v * jc[k];
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
-        if (g == 0) R[wave][i][k] = p;
-      }
-    }
-    __syncthreads();
+  const SlotIdx sq = slot_index(my_slot, a.lx, a.ly, a.lz);
+  const int ax_size = g == 0 ? a.lz : (g == 1 ? a.ly : a.lx);      // coordinate column 0 walks lz, 1 ly, 2 lx
+  auto finish = [&](long b) {                                 // wave 0: the 3 numbers of every row of block b
     if (wave == 0 && g < 3) {
       float t3 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) t3 += R[w][i][g];
+      for (int w = 0; w < 8; ++w) t3 += R[b & 1][w][i][g];
       const long n = b * 16 + i;
-      if (n >= beg && n < end) a.dcn[((long)t * a.Npad + n) * 4 + g] = t3;
+      if (n >= beg && n < end) a.dcn[((long)part * a.Npad + n) * 4 + g] = t3;
     }
-#pragma unroll
-    for (int q = 0; q < NG_NKB; ++q) { x0[q] = x1[q]; x1[q] = x2[q]; x2[q] = x3[q]; }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { w0[nt] = w1[nt]; w1[nt] = w2[nt]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { c0[k] = c1[k]; c1[k] = c2[k]; }
+  };
+#define NG_STEP(J)                                                                                                  \
+  {                                                                                                                 \
+    const long b = bb + (J);                                                                                        \
+    if (b < b1) {                                                                                                   \
+      load(b + NG_RING - 1, xr[((J) + NG_RING - 1) % NG_RING], wr[((J) + NG_RING - 1) % NG_RING],                   \
+           cr[((J) + NG_RING - 1) % NG_RING]);                                                                      \
+      f32x4 cb[2] = {zero4, zero4};                                                                                 \
+      if (kv) {                                                                                                     \
+        if (!(a.dbg & 4)) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                          \
+          cb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(up[mt], xr[J], cb[mt], 0, 0, 0);                         \
+        if (!(a.dbg & 2)) _Pragma("unroll") for (int ft = 0; ft < 2; ++ft) {                                        \
+          const bf16x4 xt = cvt4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[J], sel[ft], zero4, 0, 0, 0));          \
+          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                          \
+            dUa[ft][nt] = mfma16(xt, ng_wmask(wr[J][nt], b, g, beg, end), dUa[ft][nt]);                            \
+        }                                                                                                           \
+      }                                                                                                             \
+      if (a.dbg & 1) { dUa[0][0] += cb[0]; dUa[0][1] += cb[1]; } else {                                             \
+      if (ax_lane) {                                                                                                \
+        const Axis ax = axis_nodes(cr[J], ax_size);                                                                 \
+        NgAxis q = {ax.i0 | (ax.i1 << 8), ax.w0, ax.w1, ax.dmul};                                                   \
+        AX[b & 1][i][g] = q;                                                                                        \
+      }                                                                                                             \
+      {                                                                                                             \
+        f32x4 *pp = reinterpret_cast<f32x4 *>(&P[b & 1][wave][lane][0]);                                            \
+        pp[0] = cb[0]; pp[1] = cb[1];                                                                               \
+      }                                                                                                             \
+      __syncthreads();                                                                                              \
+      if (b > b0) finish(b - 1);                                                                                    \
+      float v = 0.f;                                                                                                \
+      _Pragma("unroll") for (int w = 0; w < 8; ++w) v += P[b & 1][w][(wave & 3) * 16 + i][(wave >> 2) * 4 + g];     \
+      const NgAxis qz = AX[b & 1][i][0], qy = AX[b & 1][i][1], qx = AX[b & 1][i][2];                                \
+      const float wx = ngx_w(qx, sq.ix), wy = ngx_w(qy, sq.iy), wz = ngx_w(qz, sq.iz);                              \
+      if (!sq.node) v = 0.f;                                                                                        \
+      float jc[3] = {v * wx * wy * ngx_d(qz, sq.iz), v * wx * ngx_d(qy, sq.iy) * wz, v * ngx_d(qx, sq.ix) * wy * wz}; \
+      _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                               \
+        float p = jc[k];                                                                                            \
+        p += __shfl_xor(p, 16, 64);                                                                                 \
+        p += __shfl_xor(p, 32, 64);                                                                                 \
+        if (g == 0) R[b & 1][wave][i][k] = p;                                                                       \
+      }                                                                                                             \
+      }                                                                                                             \
+    }                                                                                                               \
   }
+#if NG_RING == 4
+  for (long bb = b0; bb < b1; bb += 4) { NG_STEP(0) NG_STEP(1) NG_STEP(2) NG_STEP(3) }
+#else
+  for (long bb = b0; bb < b1; bb += 8) { NG_STEP(0) NG_STEP(1) NG_STEP(2) NG_STEP(3) NG_STEP(4) NG_STEP(5) NG_STEP(6) NG_STEP(7) }
+#endif
+#undef NG_STEP
+  __syncthreads();
+  finish(b1 - 1);
   // dU rows of this subject: lane (i = slot, g): features 32 kb + 16 ft + 4 g .. + 3
+  if (kv) {
 #pragma unroll
-  for (int q = 0; q < NG_NKB; ++q)
-    if (kv[q]) {
+    for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + 16 * nt + i) * a.F + (long)t * a.HP + 32 * kb[q] + 16 * ft + 4 * g) =
-              cvt4(dUa[q][ft][nt]);
-    }
+      for (int nt = 0; nt < 2; ++nt)
+        *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + 16 * nt + i) * a.F + (long)t * a.HP + 32 * kb + 16 * ft + 4 * g) =
+            cvt4(dUa[ft][nt]);
+  }
 }
 
 // dOut part: every wave takes every 8th block with all 16 columns (no exchange); the dUo partials meet in LDS at the end
-__device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, float (*P)[64][8], const int beg, const int end) {
+__device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, const int part, float (*P)[64][8], const int beg,
+                                             const int end) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -368,12 +388,11 @@ __device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, 
     vp[mt] = g < 2 ? *reinterpret_cast<const bf16x8 *>(a.Vp + (s * NG_SLOTS + 16 * mt + i) * 16 + 8 * g) : zero8;
   f32x4 acc[2] = {zero4, zero4};
   const long b0 = beg >> 4, b1 = ((long)end + 15) >> 4;
-  const int part = 2 * a.n_mod;
   for (long b = b0 + wave; b < b1; b += 8) {
     const bf16x8 x = g < 2 ? *reinterpret_cast<const bf16x8 *>(X + (b * 16 + i) * 16 + 8 * g) : zero8;
     bf16x4 w[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) w[nt] = ng_wfrag(a.wt, b, nt, i, g, beg, end);
+    for (int nt = 0; nt < 2; ++nt) w[nt] = ng_wmask(ng_wload(a.wt, b, nt, i, g), b, g, beg, end);
     const float *cp = a.coords_t + (b * 16 + i) * a.in_dim;
     const float t0 = cp[0], t1 = a.in_dim > 1 ? cp[1] : 0.f, t2 = a.in_dim > 2 ? cp[2] : 0.f;
     const bf16x4 xt = cvt4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(x, sel0, zero4, 0, 0, 0));
@@ -421,28 +440,28 @@ __device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, 
   }
 }
 
-__global__ __launch_bounds__(512) void k_node_grad(NgGradArgs a) {
-  __shared__ __attribute__((aligned(16))) float P[8][64][8];
-  __shared__ float R[8][16][4];
-  __shared__ int rng[2];
-  const int per = 2 * a.n_mod + 1;
+__global__ __launch_bounds__(512, 4) void k_node_grad(NgGradArgs a) {
+  __shared__ __attribute__((aligned(16))) float P[2][8][64][8];
+  __shared__ float R[2][8][16][4];
+  __shared__ __attribute__((aligned(16))) NgAxis AX[2][16][4];
+  const int per = 2 * a.n_mod * a.ncg + 1;
   const long s = blockIdx.x / per;
-  const int t = blockIdx.x - (int)s * per;
-  if (threadIdx.x < 2) rng[threadIdx.x] = ng_lower(a.idx, a.N, s + threadIdx.x, a.S);
-  __syncthreads();
-  const int beg = rng[0], end = rng[1];
-  if (t < 2 * a.n_mod) {
+  const int part = blockIdx.x - (int)s * per;
+  const int beg = a.offs[s], end = a.offs[s + 1];
+  if (part < per - 1) {
+    const int t = part / a.ncg, cg = part - t * a.ncg;
     if (beg >= end) {                         // subject without samples in this batch: its dU rows are zero
-      for (int q = threadIdx.x; q < NG_SLOTS * (a.HP >> 3); q += 512) {
-        const int slot = q / (a.HP >> 3), ch = q - slot * (a.HP >> 3);
+      const int cols = 256 < a.HP - 256 * cg ? 256 : a.HP - 256 * cg;
+      for (int q = threadIdx.x; q < NG_SLOTS * (cols >> 3); q += 512) {
+        const int slot = q / (cols >> 3), ch = q - slot * (cols >> 3);
         const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4 *>(a.dU + (s * NG_SLOTS + slot) * a.F + (long)t * a.HP + ch * 8) = z;
+        *reinterpret_cast<u32x4 *>(a.dU + (s * NG_SLOTS + slot) * a.F + (long)t * a.HP + 256 * cg + ch * 8) = z;
       }
       return;
     }
-    ng_body_tensor(a, s, t, P, R, beg, end);
+    ng_body_tensor(a, s, t, cg, part, P, R, AX, beg, end);
   } else {
-    ng_body_dout(a, s, P, beg, end);
+    ng_body_dout(a, s, part, P[0], beg, end);
   }
 }
 
@@ -456,7 +475,7 @@ struct NgTailArgs {
   // d table / d cond from the dT parts
   const float *dT; long part_stride; int nseg, LP, C, G, cond_dims; float *dlatents, *dcond; int g_tab, tab_cs;
   // embedding-table gradient
-  const float *coords, *dcoords, *dcn, *embed; float *dembed; const int32_t *idx; long N, Npad, S; int tf_dim, nparts, g_tf;
+  const float *coords, *dcoords, *dcn, *embed; float *dembed; const int32_t *offs; long N, Npad, S; int tf_dim, nparts, g_tf;
 };
 
 __device__ __forceinline__ void ng_tail_bias(const NgTailArgs &a, int vb) {
@@ -501,11 +520,9 @@ __device__ __forceinline__ void ng_tail_table(const NgTailArgs &a, int vb) {
 // one evaluation of the embedding gradient (embed_grad is linear in them)
 __device__ __forceinline__ void ng_tail_tf(const NgTailArgs &a, int vb) {
   __shared__ float red[4][12];
-  __shared__ int rng[2];
   const long s = vb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 2) rng[tid] = ng_lower(a.idx, a.N, s + tid, a.S);
-  __syncthreads();
+  const int rng[2] = {a.offs[s], a.offs[s + 1]};
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
@@ -569,7 +586,7 @@ bool fused_eligible(const cinema_siren_desc *d);
 bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz) {
   if (d->precision != CINEMA_PREC_BF16 || d->pk_fs < 0 || !fused_eligible(d)) return false;
   if (lx < 1 || ly < 1 || lz < 1 || lx * ly * lz >= NG_ONE_SLOT) return false;
-  if (d->HP > 32 * 8 * NG_NKB || d->in_dim != 3) return false;
+  if (d->in_dim != 3) return false;
   return d->modulated_mask != 0;
 }
 
@@ -580,9 +597,11 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   for (int i = 0; i < d->n_layers; ++i)
     if ((d->modulated_mask >> i) & 1u) p.layer_of[p.n_mod++] = i;
   p.F = p.n_mod * 2 * d->HP;
-  p.nparts = 2 * p.n_mod + 1;
+  p.ncg = (d->HP + 255) / 256;               // groups of 8 x 32 columns per tensor (k_node_grad)
+  p.nparts = 2 * p.n_mod * p.ncg + 1;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
+  p.offs = take((size_t)(S + 1) * 4);
   p.wt = take((size_t)(Npad / 16) * NG_SLOTS * 16 * 2);
   p.T = take((size_t)p.Rp * d->LP * 2);
   p.Up = take((size_t)p.Rp * p.F * 2);
@@ -623,8 +642,9 @@ extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *p
   const NgPlan p = ng_plan(d, S, Npad);
   char *w = (char *)work;
   const int G = lx * ly * lz;
-  NgWeightArgs wa = {coords, idx, embed, tf_dim, (long)N, (long)S, lx, ly, lz, (bf16_t *)(w + p.wt)};
-  hipLaunchKernelGGL(k_ng_weights, dim3((unsigned)(Npad / 16)), dim3(512), 0, s, wa);
+  NgWeightArgs wa = {coords, idx, embed, tf_dim, (long)N, (long)S, lx, ly, lz, (bf16_t *)(w + p.wt), (int32_t *)(w + p.offs),
+                     (int)(Npad / 16)};
+  hipLaunchKernelGGL(k_ng_weights, dim3((unsigned)(Npad / 16 + 1)), dim3(512), 0, s, wa);
   CINEMA_CHECK_HIP(hipGetLastError());
   NodeRowArgs r = {latents, cond_subject, (long)S, C, G, cond_dims, d->LP, (bf16_t *)(w + p.T)};
   const long total = (long)S * NODE_SLOTS * (d->LP / 8);
@@ -648,16 +668,27 @@ extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *p
   return 0;
 }
 
+static int g_ng_dbg = 0;
+extern "C" int cinema_debug_node_grad(const cinema_siren_desc *d, void *work, const void *gbuf, const float *coords_t, int64_t N,
+                                      int64_t Npad, int64_t S, int32_t lx, int32_t ly, int32_t lz, int32_t dbg, void *stream) {
+  g_ng_dbg = dbg;       // developer hook (tools/time_nodegrad.py): k_node_grad alone, with ablation bits
+  const int rc = ng_launch_grad(d, ng_plan(d, S, Npad), work, gbuf, coords_t, nullptr, N, lx, ly, lz, (hipStream_t)stream);
+  g_ng_dbg = 0;
+  return rc;
+}
+
 int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, const void *gbuf, const float *coords_t,
                    const int32_t *idx, int64_t N, int lx, int ly, int lz, hipStream_t s) {
   char *w = (char *)work;
+  (void)idx;
   NgGradArgs a = {};
+  a.dbg = g_ng_dbg;
   a.gbuf = (const bf16_t *)gbuf; a.slot_elems = p.Npad * d->HP;
   for (int i = 0; i < d->n_layers; ++i) { a.gb_s[i] = d->gb_s[i]; a.gb_t[i] = d->gb_t[i]; }
   for (int j = 0; j < p.n_mod; ++j) a.layer_of[j] = p.layer_of[j];
   a.n_mod = p.n_mod; a.dout_slot = d->n_gbuf - 1;
   a.wt = (const bf16_t *)(w + p.wt); a.Up = (const bf16_t *)(w + p.Up); a.Vp = (const bf16_t *)(w + p.Vp);
-  a.coords_t = coords_t; a.idx = idx;
+  a.coords_t = coords_t; a.offs = (const int32_t *)(w + p.offs); a.ncg = p.ncg;
   a.N = (long)N; a.Npad = p.Npad; a.S = p.S; a.HP = d->HP; a.F = p.F; a.lx = lx; a.ly = ly; a.lz = lz; a.in_dim = d->in_dim;
   a.dU = (bf16_t *)(w + p.dU); a.dUo16 = (bf16_t *)(w + p.dUo16); a.dUo32 = (float *)(w + p.dUo32); a.dcn = (float *)(w + p.dcn);
   CINEMA_REQUIRE(p.S * p.nparts < (1L << 30), "node gradients: too many subjects");
@@ -686,7 +717,7 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   }
   if (t.dembed != nullptr) {
     a.coords = t.coords; a.dcoords = t.dcoords; a.dcn = (const float *)(w + p.dcn); a.embed = t.embed; a.dembed = t.dembed;
-    a.idx = t.idx; a.tf_dim = t.tf_dim; a.nparts = p.nparts; a.g_tf = (int)p.S;
+    a.offs = (const int32_t *)(w + p.offs); a.tf_dim = t.tf_dim; a.nparts = p.nparts; a.g_tf = (int)p.S;
   }
   const int grid = a.g_red + a.g_tab + a.g_tf + a.g_bias;
   if (grid == 0) return 0;

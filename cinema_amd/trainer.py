@@ -171,6 +171,7 @@ class HotPathTrainer:
         self.side = torch.cuda.Stream(device=self.device) if self.world == 1 else None
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_prep = torch.cuda.Event()
+        self.ev_head = torch.cuda.Event()
         self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
         self.nodes = E.NodeTables()                                    # node-space tables of the nodes path
         self.ng = E.NodeGrad()                                         # work buffer of the node-space backward
@@ -241,10 +242,19 @@ class HotPathTrainer:
             k1_fwd()
             backward_only_prep()
         norm = self._union_normaliser(n, use_cw, joined)      # rank of several: started here, hidden under the forward
+        ng_on_side = use_ng and one_head and self.side is not None
+        if ng_on_side:
+            # node tables of the backward (interpolation weights, node rows, centred projections): they need the packed
+            # weights of the head launch and nothing of the forward -> beside it, joined before the backward
+            self.ev_head.record(main)
+            self.side.wait_event(self.ev_head)
+            with torch.cuda.stream(self.side):
+                E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)
+                self.ev_prep.record(self.side)
         eng.forward(n)
         if not joined:
             main.wait_event(self.ev_prep)
-        if use_ng:
+        if use_ng and not ng_on_side:
             E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
@@ -254,6 +264,8 @@ class HotPathTrainer:
         pending = self.pending if (grouped and self.train_mlp and self.world == 1) else None
         work = None
         want_tf = self.tfs.requires_grad
+        if ng_on_side:
+            main.wait_event(self.ev_prep)
         if use_ng:
             if self.cond_param is not None and self.cond_grad is None:
                 self.cond_grad = torch.zeros_like(self.cond_param)
