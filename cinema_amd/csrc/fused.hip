@@ -195,7 +195,7 @@ struct FusedFwdArgs {
 
 // NST = sample tiles of 16 per workgroup: 4 (64 samples) or 3 (48: the second, shorter round of a batch that fills the
 // chip between one and two times -- its workgroups pay the same weight stream but three quarters of the epilogues)
-template <int NST>
+template <int NST, bool FP8>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long n0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *xs = (lds_char *)smem;
@@ -270,8 +270,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long
           for (int j = 0; j < 16; ++j) sv[j] = acc[j >> 2][st][j & 3];
           pack16(sv, sp[st][0], sp[st][1]);
           if (keep) {
-            *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep)) = sp[st][0];
-            *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
+            if constexpr (FP8) {
+              *reinterpret_cast<u32x4 *>(S + ((toff_l + st * tstep) >> 1)) = pack16_fp8(sv, FP8_SCALE_ZS);
+            } else {
+              *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep)) = sp[st][0];
+              *reinterpret_cast<bf16x8 *>(S + (toff_l + st * tstep + 16u)) = sp[st][1];
+            }
           }
         }
       }
@@ -304,8 +308,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long
           bf16x8 zlo, zhi;
           pack16(zv, zlo, zhi);
           if (keep) {
-            *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep)) = zlo;
-            *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep + 16u)) = zhi;
+            if constexpr (FP8) {
+              *reinterpret_cast<u32x4 *>(Z + ((toff_l + st * tstep) >> 1)) = pack16_fp8(zv, FP8_SCALE_ZS);
+            } else {
+              *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep)) = zlo;
+              *reinterpret_cast<bf16x8 *>(Z + (toff_l + st * tstep + 16u)) = zhi;
+            }
           }
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
@@ -339,8 +347,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long
         if (keep) {
           *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep)) = ylo;
           *reinterpret_cast<bf16x8 *>(Y + (toff_l + st * tstep + 16u)) = yhi;
-          *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep)) = clo;
-          *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep + 16u)) = chi;
+          if constexpr (FP8) {
+            *reinterpret_cast<u32x4 *>(C + ((toff_l + st * tstep) >> 1)) = pack16_fp8(cv, FP8_SCALE_C);
+          } else {
+            *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep)) = clo;
+            *reinterpret_cast<bf16x8 *>(C + (toff_l + st * tstep + 16u)) = chi;
+          }
         }
         lds_char *xr = xs + (16 * st + i_l) * a.xrow;
         *(LDS_AS bf16x8 *)(xr + ((c0 ^ i_l) << 4)) = ylo;
@@ -389,9 +401,10 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long
   FUSED_TRACE(127)
 }
 
+template <bool FP8>
 __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
-  if ((int)blockIdx.x < a.g4) fused_fwd_body<4>(a, 64L * blockIdx.x);
-  else fused_fwd_body<3>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
+  if ((int)blockIdx.x < a.g4) fused_fwd_body<4, FP8>(a, 64L * blockIdx.x);
+  else fused_fwd_body<3, FP8>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
 
 
@@ -416,7 +429,7 @@ struct FusedBwdArgs {
   float om_first, om_hidden;
 };
 
-template <bool MOD, bool FIRST, int NST>
+template <bool MOD, bool FIRST, int NST, bool FP8>
 __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)[4][NST], int l, float omega, long n0,
                                              unsigned toff_l, unsigned tstep, unsigned fb_l, int i_l, int g, int lane,
                                              lds_char *gs, const lds_char *w0s, const lds_char *cs) {
@@ -434,22 +447,48 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
       for (int st = 0; st < NST; ++st) {
         const unsigned o = toff_l + st * tstep;
         float cv[16], dz[16];
-        {
+        // fp8 copies: the scales are folded into the constants below (c_inv: c, om_zs: omega for the z / s products)
+        constexpr float c_inv = FP8 ? 1.f / FP8_SCALE_C : 1.f;
+        const float om_zs = FP8 ? omega * (1.f / FP8_SCALE_ZS) : omega;
+        if constexpr (FP8) {
+          unpack16_fp8(*reinterpret_cast<const u32x4 *>(C + (o >> 1)), cv);
+        } else {
           const bf16x8 lo = *reinterpret_cast<const bf16x8 *>(C + o), hi = *reinterpret_cast<const bf16x8 *>(C + o + 16u);
 #pragma unroll
           for (int j = 0; j < 8; ++j) { cv[j] = (float)lo[j]; cv[8 + j] = (float)hi[j]; }
         }
         if constexpr (MOD) {
-          const bf16x8 zlo = *reinterpret_cast<const bf16x8 *>(Z + o), zhi = *reinterpret_cast<const bf16x8 *>(Z + o + 16u);
-          const bf16x8 slo = *reinterpret_cast<const bf16x8 *>(S + o), shi = *reinterpret_cast<const bf16x8 *>(S + o + 16u);
           float ds[16], dt[16];
+          if constexpr (FP8) {
+            // the packed words stay packed until their four values are used: three decoded tensors would hold 48 registers
+            const u32x4 zp = *reinterpret_cast<const u32x4 *>(Z + (o >> 1)), sp = *reinterpret_cast<const u32x4 *>(S + (o >> 1));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float zj = (float)(j < 8 ? zlo[j & 7] : zhi[j & 7]), sj = (float)(j < 8 ? slo[j & 7] : shi[j & 7]);
-            const float gq = acc[j >> 2][st][j & 3] * cv[j];
-            dt[j] = gq;
-            dz[j] = omega * gq * sj;
-            ds[j] = omega * gq * zj;
+            for (int h = 0; h < 8; ++h) {
+              const f32x2_t z2 = (h & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)zp[h >> 1], true)
+                                         : __builtin_amdgcn_cvt_pk_f32_fp8((int)zp[h >> 1], false);
+              const f32x2_t s2 = (h & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)sp[h >> 1], true)
+                                         : __builtin_amdgcn_cvt_pk_f32_fp8((int)sp[h >> 1], false);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int j = 2 * h + e;
+                const float gq = acc[j >> 2][st][j & 3] * cv[j] * c_inv;
+                dt[j] = gq;
+                dz[j] = om_zs * gq * s2[e];
+                ds[j] = om_zs * gq * z2[e];
+              }
+            }
+          } else {
+            const bf16x8 zlo = *reinterpret_cast<const bf16x8 *>(Z + o), zhi = *reinterpret_cast<const bf16x8 *>(Z + o + 16u);
+            const bf16x8 slo = *reinterpret_cast<const bf16x8 *>(S + o), shi = *reinterpret_cast<const bf16x8 *>(S + o + 16u);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const float zj = (float)(j < 8 ? zlo[j & 7] : zhi[j & 7]), sj = (float)(j < 8 ? slo[j & 7] : shi[j & 7]);
+              const float gq = acc[j >> 2][st][j & 3] * cv[j];
+              dt[j] = gq;
+              dz[j] = omega * gq * sj;
+              ds[j] = omega * gq * zj;
+            }
           }
           if (a.latb) {
             ts += reduce16_scatter(ds, lane);
@@ -464,7 +503,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
           *reinterpret_cast<bf16x8 *>(DT + o + 16u) = hi;
         } else {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) dz[j] = omega * acc[j >> 2][st][j & 3] * cv[j];
+          for (int j = 0; j < 16; ++j) dz[j] = (omega * c_inv) * acc[j >> 2][st][j & 3] * cv[j];
         }
         bf16x8 zl, zh;
         pack16(dz, zl, zh);
@@ -526,7 +565,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
       }
 }
 
-template <int NST>
+template <int NST, bool FP8>
 __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long n0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *gs = (lds_char *)smem;                       // g tile [64][xrow] bf16, swizzled
@@ -599,23 +638,24 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long
     __syncthreads();  // every wave has finished reading g
     if (active) {
       if (l == 0) {
-        if (mod) bwd_epilogue<true, true, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, true, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, true, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, true, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       } else {
-        if (mod) bwd_epilogue<true, false, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, false, NST>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, false, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, false, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       }
     }
     __syncthreads();  // g of the next (lower) layer is complete
   }
 }
 
+template <bool FP8>
 __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
   // behind the chain workgroups: the dOut preparation of the weight-gradient launch (reads dOut only; these workgroups
   // land on the CUs the shorter second round leaves idle)
   if ((int)blockIdx.x >= a.g_chain) { dout_prep_body<bf16_t>(a.fin, a.dout16, blockIdx.x - a.g_chain, a.g_fin); return; }
-  if ((int)blockIdx.x < a.g4) fused_bwd_body<4>(a, 64L * blockIdx.x);
-  else fused_bwd_body<3>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
+  if ((int)blockIdx.x < a.g4) fused_bwd_body<4, FP8>(a, 64L * blockIdx.x);
+  else fused_bwd_body<3, FP8>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
 
 }  // namespace
@@ -623,6 +663,7 @@ __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
 // ========================================================================================
 // host side
 // ========================================================================================
+bool fused_saved_fp8();
 static int fused_bias_floats(const cinema_siren_desc *d) {
   int n = 0;
   for (int i = 0; i < d->n_layers; ++i) n += d->HP * (((d->modulated_mask >> i) & 1u) ? 3 : 1);
@@ -765,6 +806,16 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
   return 0;
 }
 
+// Experiment, OFF by default (CINEMA_SAVED_FP8=1 turns it on; read once per process): the tensors only the backward's
+// epilogue reads (c, z, s) kept as OCP fp8 -- half the bytes of 12 of the forward's 18 saved tensors, forward 222 -> 183 us,
+// backward chain 277 -> 256 us at cfg-D.  It does NOT hold the parity bar: the 2^-4 rounding enters every dz element and
+// the sums over features / samples have random signs, so it does not average out relative to the gradient
+// (test_g5_decoder_golden[cfgT-bf16]: 5 % L2 on the first layer's weight gradient against the 1 % bound).
+bool fused_saved_fp8() {
+  static const bool on = [] { const char *e = getenv("CINEMA_SAVED_FP8"); return e && e[0] == '1'; }();
+  return on;
+}
+
 // developer hook (not part of the C ABI in include/): choose the workgroup / wave whose phase timestamps the next
 // forward launches record, and read them back
 static int g_trace_block = -1, g_trace_wave = 0;
@@ -821,10 +872,15 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   a.xsteps = ksteps(d->HP); a.lsteps = ksteps(d->LP);
   a.xrow = 64 * a.xsteps; a.lrow = 64 * a.lsteps;
   const int smem = fused_lds_bytes(d);
-  CINEMA_SMEM_ATTR(k_fused_fwd, smem);
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
-  hipLaunchKernelGGL(k_fused_fwd, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+  if (fused_saved_fp8()) {
+    CINEMA_SMEM_ATTR(k_fused_fwd<true>, smem);
+    hipLaunchKernelGGL(k_fused_fwd<true>, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+  } else {
+    CINEMA_SMEM_ATTR(k_fused_fwd<false>, smem);
+    hipLaunchKernelGGL(k_fused_fwd<false>, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+  }
   CINEMA_CHECK_HIP(hipGetLastError());
   (void)N;
   return 0;
@@ -853,7 +909,6 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
   a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
   const int smem = FUSED_TS * a.xrow + 20 * d->HP * 4 + FUSED_TS * 64 + FUSED_TS * 16;
   CINEMA_REQUIRE(smem <= 160 * 1024, "fused_backward_chain: LDS budget exceeded (%d bytes)", smem);
-  CINEMA_SMEM_ATTR(k_fused_bwd, smem);
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
   a.g_chain = a.g4 + g3;
@@ -862,7 +917,13 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
     a.dout16 = (bf16_t *)dout16;
     a.g_fin = (int)std::min<int64_t>((Npad + 511) / 512, 128);
   }
-  hipLaunchKernelGGL(k_fused_bwd, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
+  if (fused_saved_fp8()) {
+    CINEMA_SMEM_ATTR(k_fused_bwd<true>, smem);
+    hipLaunchKernelGGL(k_fused_bwd<true>, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
+  } else {
+    CINEMA_SMEM_ATTR(k_fused_bwd<false>, smem);
+    hipLaunchKernelGGL(k_fused_bwd<false>, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
+  }
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -73,3 +73,27 @@ __device__ __forceinline__ void pack16(const float (&v)[16], bf16x8 &lo, bf16x8 
   for (int j = 0; j < 8; ++j) { lo[j] = (bf16_t)v[j]; hi[j] = (bf16_t)v[8 + j]; }
 }
 
+
+// OCP fp8 (e4m3) copies of the tensors only the backward's epilogue reads (c, z, s): 16 values = one 16-byte vector.
+// The values are scaled into the middle of the format's range first (the backward folds the inverse into its constants).
+__device__ __forceinline__ u32x4 pack16_fp8(const float (&v)[16], float scale) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * scale, v[4 * q + 1] * scale, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * scale, v[4 * q + 3] * scale, w, true);
+    o[q] = (unsigned)w;
+  }
+  return o;
+}
+__device__ __forceinline__ void unpack16_fp8(const u32x4 &p, float (&v)[16]) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)p[q], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)p[q], true);
+    v[4 * q] = lo[0]; v[4 * q + 1] = lo[1]; v[4 * q + 2] = hi[0]; v[4 * q + 3] = hi[1];
+  }
+}
+#define FP8_SCALE_C 256.f
+#define FP8_SCALE_ZS 16.f
