@@ -14,6 +14,7 @@
 // Work buffer (caller-owned, cinema_nodegrad_work_bytes; zeroed once by the caller, rows >= S*32 stay zero):
 //   offs   int32 [S + 1]            first row of every subject in the grouped batch
 //   wt     bf16 [Npad/16][32][16]   interpolation weights, per 16-row block, slot-major (MFMA operand order)
+//   wrow   bf16 [Npad][32]          the same weights row-major; axt int32 [Npad][3][4]: the rows' interpolation axes
 //   T      bf16 [Rp][LP]            node rows of the table (+ the subject's conditions), Rp = S*32 rounded up to 128
 //   Up     bf16 [S*32][F]           centred projections U', F = n_mod * 2 * HP
 //   Vp     bf16 [S*32][16]          the same through final_linear.weight[:, H:]
@@ -30,7 +31,7 @@ struct NgPlan {
   long S, Npad, Rp;
   int n_mod, F, nparts, ncg, HP, LP;
   int layer_of[CINEMA_MAX_LAYERS];
-  size_t offs, wt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
+  size_t offs, wt, wrow, axt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
 };
 bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz);
 NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad);

@@ -69,6 +69,7 @@ __device__ __forceinline__ int ng_lower(const int32_t *idx, long N, long key, lo
 struct NgWeightArgs {
   const float *coords; const int32_t *idx; const float *embed; int tf_dim; long N, S; int lx, ly, lz; bf16_t *wt;
   int32_t *offs; int nblk;       // the workgroup behind the nblk row blocks writes offs[0..S]: first row of every subject
+  bf16_t *wrow; int32_t *axt;    // the same weights row-major [Npad][32]; interpolation axes [Npad][8 words]
 };
 __global__ __launch_bounds__(512) void k_ng_weights(NgWeightArgs a) {
   __shared__ float ct[16][4];
@@ -104,6 +105,15 @@ __global__ __launch_bounds__(512) void k_ng_weights(NgWeightArgs a) {
   float w = 0.f;
   if (ct[i][3] != 0.f) w = slot == NG_ONE_SLOT ? 1.f : slot_weight(ct[i][0], ct[i][1], ct[i][2], a.lx, a.ly, a.lz, slot);
   a.wt[(blk * NG_SLOTS + slot) * 16 + i] = (bf16_t)w;
+  a.wrow[(blk * 16 + i) * NG_SLOTS + slot] = (bf16_t)w;
+  if (tid < 48) {        // (row, coordinate column): column 0 walks lz, 1 ly, 2 lx
+    const int r = tid / 3, ax = tid - 3 * r;
+    const Axis q = axis_nodes(ct[r][ax], ax == 0 ? a.lz : (ax == 1 ? a.ly : a.lx));
+    int32_t *o = a.axt + (blk * 16 + r) * 8 + 2 * ax;      // {i0 | i1 << 8 | (clip inactive) << 16, w0}; words 6, 7 unused
+    o[0] = q.i0 | (q.i1 << 8) | (q.dmul != 0.f ? 1 << 16 : 0);
+    o[1] = __float_as_int(q.w0);
+    if (ax == 0) { o[6] = 0; o[7] = 0; }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_ng_rows(NodeRowArgs a) { node_rows_body(a, blockIdx.x, gridDim.x); }
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void k_ng_project(NgProjArgs a) {
 struct NgGradArgs {
   const bf16_t *gbuf; long slot_elems; int gb_s[CINEMA_MAX_LAYERS], gb_t[CINEMA_MAX_LAYERS], layer_of[CINEMA_MAX_LAYERS];
   int n_mod, dout_slot, ncg;
-  const bf16_t *wt, *Up, *Vp; const float *coords_t; const int32_t *offs;
+  const bf16_t *wt, *wrow, *Up, *Vp; const int32_t *axt; const float *coords_t; const int32_t *offs;
   long N, Npad, S; int HP, F, lx, ly, lz, in_dim;
   bf16_t *dU, *dUo16; float *dUo32, *dcn;
   int dbg;      // developer ablations (cinema_debug_node_grad): 1 = no exchange / d coords, 2 = no dU products, 4 = no dwn products
@@ -238,135 +248,215 @@ __device__ __forceinline__ bf16x4 ng_wmask(bf16x4 w, long b, int g, int beg, int
   return w;
 }
 
-// One tensor t = (modulated layer, half) and one group cg of 8 x 32 columns: wave w owns the 32-column block 8 cg + w.
-// Loads run three row blocks ahead through a ring of four register sets with STATIC slots (a rotating copy would
-// make every load wait at the copy); one barrier per row block (P, R and the axis table are double-buffered, the last
-// sum of a block is taken one block later).  The interpolation axes of the block's 16 rows (3 per row: nodes, weights,
-// d u / d coordinate) are worked out once, by 48 lanes of wave 1, and shared through LDS.
-struct NgAxis { int nodes; float w0, w1, dmul; };      // nodes = i0 | i1 << 8
-__device__ __forceinline__ float ngx_w(const NgAxis &a, int i) {
-  const int i0 = a.nodes & 255, i1 = a.nodes >> 8;
-  return (i == i0 ? a.w0 : 0.f) + ((i == i1 && i1 != i0) ? a.w1 : 0.f);
+// One tensor t = (modulated layer, half) and one group cg of 256 columns.  The X rows go global -> LDS by LDS-DMA in
+// tiles of 32 rows x 512 B (whole 512-B row pieces per wave-instruction: coalesced, no staging registers), three tiles in
+// a ring, two in flight; the tile's interpolation weights and axes ride along.  Per tile and ONE barrier: every wave
+// multiplies its 32 columns into dU (operands by transposing LDS reads, k = 32 rows), and the dwn products of the tile
+// (2 x 16 rows, 2 x 16 slots, all 256 columns -- no partial sums to exchange) are pipelined over the eight waves: four
+// take the MFMA stage of this tile, the other four apply d w / d coords to what they multiplied one tile earlier; the two
+// slot halves of a row meet in LDS and are stored one tile later.  DMA completion is counted by hand (siren.hip, k_dw256).
+#define NG_TR 32                               // rows per tile
+#define NG_D 3
+#define NG_XT (NG_TR * 512)                    // X tile
+#define NG_WT (NG_TR * 64)                     // weights of the tile, row-major [row][32 slots] bf16
+#define NG_SLOT (NG_XT + NG_WT)
+#define NG_UP 16384                            // U' image: 32 rows x 512 B
+#define NG_AT 1024                             // axes of the tile: 32 rows x 8 words
+#define NG_AD 4                                // axis ring (read one tile later than the X ring)
+#define NG_RB (2 * 2 * 2 * 16 * 4 * 4)         // [parity][row half][slot half][row][4] fp32
+#define NG_SMEM (NG_UP + NG_D * NG_SLOT + NG_AD * NG_AT + NG_RB)
+// 16-B chunk c of row r of a 512-B-row image sits at position c ^ key(r): 16 rows reading one chunk (ds_read_b128) and
+// 8 rows x 2 chunks of a transposing read both cover every bank once
+__device__ __forceinline__ int ng_key(int r) { return ((r & 7) << 1) | ((r >> 3) & 1); }
+__device__ __forceinline__ void ng_glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ float ngx_d(const NgAxis &a, int i) {
-  const int i0 = a.nodes & 255, i1 = a.nodes >> 8;
-  return (((i == i1) ? 1.f : 0.f) - ((i == i0) ? 1.f : 0.f)) * a.dmul;
+__device__ __forceinline__ void ng_wait(int n) {      // s_waitcnt vmcnt(n), n wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+  }
+}
+// rows row0, row0 + 1 (image rows ir0, ir0 + 1) of src [rows][ld], columns c0 .. c0 + 255 -> 1 KB of a swizzled image
+__device__ __forceinline__ void ng_stage2(const bf16_t *src, long ld, long row0, int ir0, int c0, int climit, lds_char *image, int lane) {
+  const int r = lane >> 5, p = lane & 31;
+  int col = c0 + ((p ^ ng_key(ir0 + r)) << 3);
+  if (col + 8 > climit) col = c0;
+  ng_glds16(src + (row0 + r) * ld + col, (unsigned)(__SIZE_TYPE__)(image + ir0 * 512));
+}
+// transposing read of 16 columns x 32 rows (k = row) of a swizzled 512-B-row image: an MFMA operand with k = rows
+__device__ __forceinline__ bf16x8 ng_tr_frag(const lds_char *image, int colbase, int lane) {
+  typedef LDS_AS s16x4 lds_s16x4;
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r0 = 8 * g + q, colbyte = (colbase + 4 * p) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4 *)(image + r0 * 512 + ((((colbyte >> 4) ^ ng_key(r0)) << 4) | (colbyte & 15))));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4 *)(image + (r0 + 4) * 512 + ((((colbyte >> 4) ^ ng_key(r0 + 4)) << 4) | (colbyte & 15))));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// the same from the tile's weight rows [32 rows][32 slots] (64-B rows, not swizzled)
+__device__ __forceinline__ bf16x8 ng_tr_wfrag(const lds_char *wt, int slotbase, int lane) {
+  typedef LDS_AS s16x4 lds_s16x4;
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r0 = 8 * g + q;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(wt + r0 * 64 + (slotbase + 4 * p) * 2));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(wt + (r0 + 4) * 64 + (slotbase + 4 * p) * 2));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
 }
 
 __device__ __forceinline__ void ng_body_tensor(const NgGradArgs &a, const long s, const int t, const int cg, const int part,
-                                               float (*P)[8][64][8], float (*R)[8][16][4], NgAxis (*AX)[16][4], const int beg,
-                                               const int end) {
+                                               lds_char *smem, const int beg, const int end) {
+  lds_char *UP = smem, *XR = UP + NG_UP, *AR = XR + NG_D * NG_SLOT;
+  LDS_AS float *RR = (LDS_AS float *)(AR + NG_AD * NG_AT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int jm = t >> 1, half = t & 1, layer = a.layer_of[jm];
   const bf16_t *X = a.gbuf + a.slot_elems * (half ? a.gb_t[layer] : a.gb_s[layer]);
-  const int nkb = a.HP >> 5;
-  const bool kv = 8 * cg + wave < nkb;                       // wave-uniform: this wave's column block exists
-  const int kb = kv ? 8 * cg + wave : 0;
+  const int c0 = 256 * cg;
+  const int cols = a.HP - c0 < 256 ? a.HP - c0 : 256;
+  const int nkk = cols >> 5;
+  const bool kv = wave < nkk;                                // wave-uniform: this wave's 32-column block exists
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  bf16x8 sel[2];
+  const long b0 = beg / NG_TR, b1 = ((long)end + NG_TR - 1) / NG_TR;
+  const int nt = (int)(b1 - b0);
+  const int per_tile = wave == 0 ? 4 : (wave == 1 ? 3 : 2); // DMA instructions of this wave per tile
+  auto stage_tile = [&](int k) {
+    const long bb = b0 + k;
+    lds_char *sl = XR + (k % NG_D) * NG_SLOT;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sel[0][e] = (bf16_t)((8 * g + e == i) ? 1.f : 0.f);
-    sel[1][e] = (bf16_t)((8 * g + e == 16 + i) ? 1.f : 0.f);
-  }
-  bf16x8 up[2];
-  f32x4 dUa[2][2];
+    for (int j = 0; j < 2; ++j) ng_stage2(X, a.HP, bb * NG_TR + 4 * wave + 2 * j, 4 * wave + 2 * j, c0, a.HP, sl, lane);
+    if (wave == 0) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    up[mt] = *reinterpret_cast<const bf16x8 *>(a.Up + (s * NG_SLOTS + 16 * mt + i) * a.F + (long)t * a.HP + 32 * kb + 8 * g);
-    dUa[0][mt] = zero4; dUa[1][mt] = zero4;
-  }
-  const long b0 = beg >> 4, b1 = ((long)end + 15) >> 4;
-#ifndef NG_RING
-#define NG_RING 4
-#endif
-  bf16x8 xr[NG_RING];
-  bf16x4 wr[NG_RING][2];
-  float cr[NG_RING];                  // wave 1, lane (i, g < 3): coordinate column g of row i
-  const bool ax_lane = wave == 1 && g < 3;
-  auto load = [&](long b, bf16x8 &x, bf16x4 (&w)[2], float &c) {
-    const long bb = b < b1 ? b : b1 - 1;
-    if (ax_lane) c = a.coords_t[(bb * 16 + i) * 3 + g];
-    x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(X + (bb * 16 + i) * a.HP + 32 * kb + 8 * g));
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) w[nt] = ng_wload(a.wt, bb, nt, i, g);
-  };
-#pragma unroll
-  for (int q = 0; q < NG_RING - 1; ++q) load(b0 + q, xr[q], wr[q], cr[q]);
-  // the slot this lane finishes after the exchange: wave -> (slot tile, lane group), lane group g -> accumulator register
-  const int my_slot = 16 * (wave >> 2) + 4 * (wave & 3) + g;
-  const SlotIdx sq = slot_index(my_slot, a.lx, a.ly, a.lz);
-  const int ax_size = g == 0 ? a.lz : (g == 1 ? a.ly : a.lx);      // coordinate column 0 walks lz, 1 ly, 2 lx
-  auto finish = [&](long b) {                                 // wave 0: the 3 numbers of every row of block b
-    if (wave == 0 && g < 3) {
-      float t3 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) t3 += R[b & 1][w][i][g];
-      const long n = b * 16 + i;
-      if (n >= beg && n < end) a.dcn[((long)part * a.Npad + n) * 4 + g] = t3;
+      for (int j = 0; j < 2; ++j)
+        ng_glds16(a.wrow + (bb * NG_TR + 16 * j) * NG_SLOTS + lane * 8, (unsigned)(__SIZE_TYPE__)(sl + NG_XT + j * 1024));
     }
+    if (wave == 1) ng_glds16(a.axt + bb * NG_TR * 8 + lane * 4, (unsigned)(__SIZE_TYPE__)(AR + (k % NG_AD) * NG_AT));
   };
-#define NG_STEP(J)                                                                                                  \
-  {                                                                                                                 \
-    const long b = bb + (J);                                                                                        \
-    if (b < b1) {                                                                                                   \
-      load(b + NG_RING - 1, xr[((J) + NG_RING - 1) % NG_RING], wr[((J) + NG_RING - 1) % NG_RING],                   \
-           cr[((J) + NG_RING - 1) % NG_RING]);                                                                      \
-      f32x4 cb[2] = {zero4, zero4};                                                                                 \
-      if (kv) {                                                                                                     \
-        if (!(a.dbg & 4)) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                          \
-          cb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(up[mt], xr[J], cb[mt], 0, 0, 0);                         \
-        if (!(a.dbg & 2)) _Pragma("unroll") for (int ft = 0; ft < 2; ++ft) {                                        \
-          const bf16x4 xt = cvt4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[J], sel[ft], zero4, 0, 0, 0));          \
-          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                          \
-            dUa[ft][nt] = mfma16(xt, ng_wmask(wr[J][nt], b, g, beg, end), dUa[ft][nt]);                            \
-        }                                                                                                           \
-      }                                                                                                             \
-      if (a.dbg & 1) { dUa[0][0] += cb[0]; dUa[0][1] += cb[1]; } else {                                             \
-      if (ax_lane) {                                                                                                \
-        const Axis ax = axis_nodes(cr[J], ax_size);                                                                 \
-        NgAxis q = {ax.i0 | (ax.i1 << 8), ax.w0, ax.w1, ax.dmul};                                                   \
-        AX[b & 1][i][g] = q;                                                                                        \
-      }                                                                                                             \
-      {                                                                                                             \
-        f32x4 *pp = reinterpret_cast<f32x4 *>(&P[b & 1][wave][lane][0]);                                            \
-        pp[0] = cb[0]; pp[1] = cb[1];                                                                               \
-      }                                                                                                             \
-      __syncthreads();                                                                                              \
-      if (b > b0) finish(b - 1);                                                                                    \
-      float v = 0.f;                                                                                                \
-      _Pragma("unroll") for (int w = 0; w < 8; ++w) v += P[b & 1][w][(wave & 3) * 16 + i][(wave >> 2) * 4 + g];     \
-      const NgAxis qz = AX[b & 1][i][0], qy = AX[b & 1][i][1], qx = AX[b & 1][i][2];                                \
-      const float wx = ngx_w(qx, sq.ix), wy = ngx_w(qy, sq.iy), wz = ngx_w(qz, sq.iz);                              \
-      if (!sq.node) v = 0.f;                                                                                        \
-      float jc[3] = {v * wx * wy * ngx_d(qz, sq.iz), v * wx * ngx_d(qy, sq.iy) * wz, v * ngx_d(qx, sq.ix) * wy * wz}; \
-      _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                               \
-        float p = jc[k];                                                                                            \
-        p += __shfl_xor(p, 16, 64);                                                                                 \
-        p += __shfl_xor(p, 32, 64);                                                                                 \
-        if (g == 0) R[b & 1][wave][i][k] = p;                                                                       \
-      }                                                                                                             \
-      }                                                                                                             \
-    }                                                                                                               \
+  // U' rows of this subject and tensor: 32 rows x 256 columns, two instructions per wave
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ng_stage2(a.Up + (long)t * a.HP, a.F, s * NG_SLOTS + 4 * wave + 2 * j, 4 * wave + 2 * j, c0, a.HP, UP, lane);
+  for (int k = 0; k < NG_D - 1 && k < nt; ++k) stage_tile(k);
+  // dwn roles of this wave: rows 16 h .. + 15 of a tile, slots 16 mt .. + 15, tiles of parity tp in the MFMA stage
+  const int h = wave & 1, mt = (wave >> 1) & 1, tp = wave >> 2;
+  int sl4[4];                                                // the lane's 4 slots 16 mt + 4 g + r -> (ix, iy, iz, is a node)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const SlotIdx sq = slot_index(16 * mt + 4 * g + r, a.lx, a.ly, a.lz);
+    sl4[r] = sq.ix | (sq.iy << 8) | (sq.iz << 16) | (sq.node ? 1 << 24 : 0);
   }
-#if NG_RING == 4
-  for (long bb = b0; bb < b1; bb += 4) { NG_STEP(0) NG_STEP(1) NG_STEP(2) NG_STEP(3) }
-#else
-  for (long bb = b0; bb < b1; bb += 8) { NG_STEP(0) NG_STEP(1) NG_STEP(2) NG_STEP(3) NG_STEP(4) NG_STEP(5) NG_STEP(6) NG_STEP(7) }
-#endif
-#undef NG_STEP
-  __syncthreads();
-  finish(b1 - 1);
-  // dU rows of this subject: lane (i = slot, g): features 32 kb + 16 ft + 4 g .. + 3
+  const float dmv[3] = {0.5f * (float)(a.lz - 1), 0.5f * (float)(a.ly - 1), 0.5f * (float)(a.lx - 1)};
+  f32x4 dUa[2][2] = {{zero4, zero4}, {zero4, zero4}};
+  f32x4 cb = zero4;                                          // dwn of the tile this wave multiplied last
+  for (int k = 0; k < nt + 2; ++k) {
+    if (k < nt) {
+      const int rem = nt - 1 - k < NG_D - 2 ? nt - 1 - k : NG_D - 2;    // tiles that may stay in flight behind tile k
+      ng_wait(rem * per_tile);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (k + NG_D - 1 < nt) stage_tile(k + NG_D - 1);         // its X slot held tile k - 1: every wave is past it
+    const lds_char *xt = XR + (k % NG_D) * NG_SLOT;
+    if (k < nt && kv && !(a.dbg & 2)) {
+      const long b = b0 + k;
+      bf16x8 wf[2];
+#pragma unroll
+      for (int nt2 = 0; nt2 < 2; ++nt2) {
+        wf[nt2] = ng_tr_wfrag(xt + NG_XT, 16 * nt2, lane);
+        if (NG_TR * b < beg || NG_TR * b + NG_TR > end) {    // a subject's first and last tile: rows of its neighbours
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const long n = NG_TR * b + 8 * g + e;
+            if (n < beg || n >= end) wf[nt2][e] = (bf16_t)0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const bf16x8 xf = ng_tr_frag(xt, 32 * wave + 16 * ft, lane);
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) dUa[ft][nt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf[nt2], dUa[ft][nt2], 0, 0, 0);
+      }
+    }
+    if (a.dbg & 1) continue;
+    if ((k & 1) == tp) {
+      // finish the tile of two steps ago (its slot halves were left in LDS one step ago), then multiply tile k
+      if (mt == 0 && k >= 2) {
+        const long n = (b0 + k - 2) * NG_TR + 16 * h + i;
+        const LDS_AS float *r0 = RR + (((k & 1) * 2 + h) * 2) * 64 + i * 4;
+        if (g < 3 && n >= beg && n < end) a.dcn[((long)part * a.Npad + n) * 4 + g] = r0[g] + r0[64 + g];
+      }
+      if (k < nt) {
+        f32x4 cb0 = zero4, cb1 = zero4;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+          if (kk < nkk) {
+            const int pos0 = ((4 * kk + g) ^ ng_key(i)) << 4, pos1 = ((4 * kk + 4 + g) ^ ng_key(i)) << 4;
+            const bf16x8 xb0 = *(const LDS_AS bf16x8 *)(xt + (16 * h + i) * 512 + pos0);
+            const bf16x8 xb1 = *(const LDS_AS bf16x8 *)(xt + (16 * h + i) * 512 + pos1);
+            const bf16x8 ua0 = *(const LDS_AS bf16x8 *)(UP + (16 * mt + i) * 512 + pos0);
+            const bf16x8 ua1 = *(const LDS_AS bf16x8 *)(UP + (16 * mt + i) * 512 + pos1);
+            cb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua0, xb0, cb0, 0, 0, 0);
+            cb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua1, xb1, cb1, 0, 0, 0);
+          }
+        }
+        cb = cb0 + cb1;
+      }
+    } else if (k >= 1 && k - 1 < nt) {
+      // d w / d coords on the dwn of tile k - 1 (this wave's rows and slots): axes of row 16 h + i from the axis ring
+      const lds_char *at = AR + ((k - 1) % NG_AD) * NG_AT + (16 * h + i) * 32;
+      const u32x4 r01 = *(const LDS_AS u32x4 *)at;
+      const unsigned r2n = *(const LDS_AS unsigned *)(at + 16), r2w = *(const LDS_AS unsigned *)(at + 20);
+      const unsigned nd[3] = {r01[0], r01[2], r2n};          // 0: lz axis (coordinate column 0), 1: ly, 2: lx
+      const float w0v[3] = {__uint_as_float(r01[1]), __uint_as_float(r01[3]), __uint_as_float(r2w)};
+      int n0[3], n1[3]; float w0[3], w1[3], dm[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        n0[q] = nd[q] & 255; n1[q] = (nd[q] >> 8) & 255;
+        const bool two = n1[q] != n0[q];
+        w0[q] = w0v[q];
+        w1[q] = two ? 1.f - w0v[q] : 0.f;
+        dm[q] = (two && (nd[q] >> 16)) ? dmv[q] : 0.f;
+      }
+      float dc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int id[3] = {(sl4[r] >> 16) & 255, (sl4[r] >> 8) & 255, sl4[r] & 255};     // iz, iy, ix
+        const float v = (sl4[r] >> 24) ? cb[r] : 0.f;
+        float wv[3], dv[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const bool e0 = id[q] == n0[q], e1 = id[q] == n1[q];
+          wv[q] = (e0 ? w0[q] : 0.f) + (e1 ? w1[q] : 0.f);
+          dv[q] = (e1 ? dm[q] : 0.f) - (e0 ? dm[q] : 0.f);
+        }
+        dc[0] += v * wv[2] * wv[1] * dv[0];
+        dc[1] += v * wv[2] * dv[1] * wv[0];
+        dc[2] += v * dv[2] * wv[1] * wv[0];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        dc[q] += __shfl_xor(dc[q], 16, 64);
+        dc[q] += __shfl_xor(dc[q], 32, 64);
+      }
+      if (g < 3) RR[((((k - 1) & 1) * 2 + h) * 2 + mt) * 64 + i * 4 + g] = dc[g];
+    }
+  }
+  // dU rows of this subject: lane (i = slot, g): features c0 + 32 wave + 16 ft + 4 g .. + 3
   if (kv) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + 16 * nt + i) * a.F + (long)t * a.HP + 32 * kb + 16 * ft + 4 * g) =
-            cvt4(dUa[ft][nt]);
+      for (int nt2 = 0; nt2 < 2; ++nt2)
+        *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + 16 * nt2 + i) * a.F + (long)t * a.HP + c0 + 32 * wave + 16 * ft + 4 * g) =
+            cvt4(dUa[ft][nt2]);
   }
 }
 
@@ -441,9 +531,8 @@ __device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, 
 }
 
 __global__ __launch_bounds__(512, 4) void k_node_grad(NgGradArgs a) {
-  __shared__ __attribute__((aligned(16))) float P[2][8][64][8];
-  __shared__ float R[2][8][16][4];
-  __shared__ __attribute__((aligned(16))) NgAxis AX[2][16][4];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_char *smem = (lds_char *)smem_raw;
   const int per = 2 * a.n_mod * a.ncg + 1;
   const long s = blockIdx.x / per;
   const int part = blockIdx.x - (int)s * per;
@@ -459,9 +548,9 @@ __global__ __launch_bounds__(512, 4) void k_node_grad(NgGradArgs a) {
       }
       return;
     }
-    ng_body_tensor(a, s, t, cg, part, P, R, AX, beg, end);
+    ng_body_tensor(a, s, t, cg, part, smem, beg, end);
   } else {
-    ng_body_dout(a, s, part, P[0], beg, end);
+    ng_body_dout(a, s, part, (float (*)[64][8])smem_raw, beg, end);
   }
 }
 
@@ -603,6 +692,8 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
   p.offs = take((size_t)(S + 1) * 4);
   p.wt = take((size_t)(Npad / 16) * NG_SLOTS * 16 * 2);
+  p.wrow = take((size_t)Npad * NG_SLOTS * 2 + 1024);
+  p.axt = take((size_t)Npad * 8 * 4 + 1024);
   p.T = take((size_t)p.Rp * d->LP * 2);
   p.Up = take((size_t)p.Rp * p.F * 2);
   p.Vp = take((size_t)p.Rp * 16 * 2);
@@ -643,7 +734,7 @@ extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *p
   char *w = (char *)work;
   const int G = lx * ly * lz;
   NgWeightArgs wa = {coords, idx, embed, tf_dim, (long)N, (long)S, lx, ly, lz, (bf16_t *)(w + p.wt), (int32_t *)(w + p.offs),
-                     (int)(Npad / 16)};
+                     (int)(Npad / 16), (bf16_t *)(w + p.wrow), (int32_t *)(w + p.axt)};
   hipLaunchKernelGGL(k_ng_weights, dim3((unsigned)(Npad / 16 + 1)), dim3(512), 0, s, wa);
   CINEMA_CHECK_HIP(hipGetLastError());
   NodeRowArgs r = {latents, cond_subject, (long)S, C, G, cond_dims, d->LP, (bf16_t *)(w + p.T)};
@@ -687,12 +778,13 @@ int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   for (int i = 0; i < d->n_layers; ++i) { a.gb_s[i] = d->gb_s[i]; a.gb_t[i] = d->gb_t[i]; }
   for (int j = 0; j < p.n_mod; ++j) a.layer_of[j] = p.layer_of[j];
   a.n_mod = p.n_mod; a.dout_slot = d->n_gbuf - 1;
-  a.wt = (const bf16_t *)(w + p.wt); a.Up = (const bf16_t *)(w + p.Up); a.Vp = (const bf16_t *)(w + p.Vp);
+  a.wt = (const bf16_t *)(w + p.wt); a.wrow = (const bf16_t *)(w + p.wrow); a.axt = (const int32_t *)(w + p.axt); a.Up = (const bf16_t *)(w + p.Up); a.Vp = (const bf16_t *)(w + p.Vp);
   a.coords_t = coords_t; a.offs = (const int32_t *)(w + p.offs); a.ncg = p.ncg;
   a.N = (long)N; a.Npad = p.Npad; a.S = p.S; a.HP = d->HP; a.F = p.F; a.lx = lx; a.ly = ly; a.lz = lz; a.in_dim = d->in_dim;
   a.dU = (bf16_t *)(w + p.dU); a.dUo16 = (bf16_t *)(w + p.dUo16); a.dUo32 = (float *)(w + p.dUo32); a.dcn = (float *)(w + p.dcn);
   CINEMA_REQUIRE(p.S * p.nparts < (1L << 30), "node gradients: too many subjects");
-  hipLaunchKernelGGL(k_node_grad, dim3((unsigned)(p.S * p.nparts)), dim3(512), 0, s, a);
+  CINEMA_SMEM_ATTR(k_node_grad, NG_SMEM);
+  hipLaunchKernelGGL(k_node_grad, dim3((unsigned)(p.S * p.nparts)), dim3(512), NG_SMEM, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }
