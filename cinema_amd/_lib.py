@@ -74,7 +74,7 @@ SIGNATURES = {
                                          _P, _I32, _P],
     "cinema_cond_table_bwd": [_P, _P, _I64, _I64, _I32, _P, _P],
     "cinema_step_head": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
-                         _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
+                         _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P],
     "cinema_affine_trilerp_bwd": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
                                   _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_affine_trilerp_bwd_noalloc": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32,
@@ -93,7 +93,7 @@ SIGNATURES = {
     "cinema_nodegrad_eligible": [C.POINTER(SirenDesc), _I32, _I32, _I32],
     "cinema_nodegrad_work_bytes": [C.POINTER(SirenDesc), _I64, _I64],
     "cinema_nodegrad_prepare": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
-                                _P, _P],
+                                _P, _I32, _P],
     "cinema_siren_backward_nodegrad": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _I32,
                                        _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "cinema_sample_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _F, _F, _P, _P, _P, _P],

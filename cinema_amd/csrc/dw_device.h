@@ -27,7 +27,20 @@ __device__ __forceinline__ void dw256_reduce_body(const Dw256Args &a, int vbid) 
   if (h0 + row >= pr.M || c0 + col >= pr.K) return;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   const float *src = a.slab + ((size_t)pr.slab0 + (size_t)t * pr.nsplit) * (256 * 256) + row * 256 + col;
-  for (int sp = 0; sp < pr.nsplit; ++sp) {
+  // all splits are requested before the first one is added (a rolled loop pays one memory round trip per split); the
+  // sum keeps the split order
+  int sp = 0;
+  for (; sp + 4 <= pr.nsplit; sp += 4) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[2 * u] = *reinterpret_cast<const f32x4 *>(src + (size_t)(sp + u) * (256 * 256));
+      v[2 * u + 1] = *reinterpret_cast<const f32x4 *>(src + (size_t)(sp + u) * (256 * 256) + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s0 += v[2 * u]; s1 += v[2 * u + 1]; }
+  }
+  for (; sp < pr.nsplit; ++sp) {
     s0 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256));
     s1 += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * (256 * 256) + 4);
   }

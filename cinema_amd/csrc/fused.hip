@@ -8,6 +8,7 @@
 // straight from global memory (L2) through a register ring fed by one contiguous per-wave weight stream
 // (fused.h), its B fragments are conflict-free ds_read_b128 from the shared x / lat tiles.
 #include "fused.h"
+#include "nodegrad.h"
 #include "gemm_engine.h"
 #include <algorithm>
 #include <cstdlib>
@@ -16,6 +17,7 @@ namespace {
 
 #include "k1_device.h"
 #include "step_device.h"
+#include "noderows_device.h"
 #include "dw_device.h"
 
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
@@ -138,14 +140,15 @@ __global__ __launch_bounds__(256) void k_pack_side(PackSideArgs a) { pack_side_b
 // shadow of the latent table and the per-step clearing are independent, but as separate kernels they either share a
 // stream (23 + 17 us in a row for the two the forward waits for) or need a second stream, whose join costs 6-10 us of
 // idle queue.  Block ranges: step_prepare (the longest chain of dependent loads; optional, g_pr = 0) | K1 forward chunks |
-// backward-only transposes (64 workgroups each) | weight streams | side block | shadow tiles (optional, g_nm = 0).
+// backward-only transposes (64 workgroups each) | weight streams | side block | node rows of the node-space backward
+// (optional, g_nr = 0) | shadow tiles (optional, g_nm = 0).
 #define HEAD_MAX_JOBS 16
 struct StepHeadArgs {
   PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1;
   PackJob job[HEAD_MAX_JOBS]; void *packed;
   const float *nm_lat; float *nm_shadow; long nm_S; int nm_C, nm_G;
-  StepPrepareArgs pr;
-  int g_k1, g_ps, g_sd, g_job, g_nm, g_pr;
+  StepPrepareArgs pr; NodeRowsCArgs nr;
+  int g_k1, g_ps, g_sd, g_job, g_nm, g_pr, g_nr;
 };
 __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   int b = blockIdx.x;                            // workgroup-uniform dispatch; the longest dependent-load chains first
@@ -159,6 +162,8 @@ __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   b -= a.g_ps;
   if (b < a.g_sd) { pack_side_body(a.sd, b, a.g_sd); return; }
   b -= a.g_sd;
+  if (b < a.g_nr) { node_rows_centred_body(a.nr, b); return; }
+  b -= a.g_nr;
   node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
 }
 
@@ -756,7 +761,7 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
                                 const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                                 int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
                                 int32_t cond_dims, int32_t cond_by_subject, float *coords_t, void *lat_out, float *shadow,
-                                float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const uint8_t *labels,
+                                void *node_work, float *dcoords, int64_t n_dcoords, float *sums, const int64_t *voxel, const uint8_t *labels,
                                 int64_t V, int32_t n_cls, const float *class_w, float *scratch, void *stream) {
   CINEMA_REQUIRE(d && params && packed && coords && idx && latents && coords_t && lat_out, "cinema_step_head: null argument");
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "cinema_step_head: needs the activation-stationary bf16 path (hidden <= 512)");
@@ -793,6 +798,14 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
     CINEMA_REQUIRE(nwg < (1L << 24), "cinema_step_head: latent table too large (%ld tiles)", nwg);
     a.g_nm = (int)nwg;
   }
+  if (node_work != nullptr) {                  // T and Tc of the node-space backward (cinema_nodegrad_prepare, flags & 1)
+    CINEMA_REQUIRE(cond_by_subject || cond_dims == 0, "cinema_step_head: node rows need per-subject conditions");
+    CINEMA_REQUIRE(ng_eligible(d, lx, ly, lz) && d->LP % 32 == 0, "cinema_step_head: node rows need a stack cinema_nodegrad_eligible accepts");
+    const NgPlan p = ng_plan(d, S, 128);       // the places of T and Tc do not depend on Npad
+    a.nr = NodeRowsCArgs{latents, cond, (long)S, C, lx * ly * lz, cond_dims, d->LP, (bf16_t *)((char *)node_work + p.T),
+                         (bf16_t *)((char *)node_work + p.Tc)};
+    a.g_nr = (int)(S * (d->LP / 32));
+  }
   if (sums != nullptr) {
     CINEMA_REQUIRE(scratch != nullptr && n_dcoords >= 0 && (dcoords != nullptr || n_dcoords == 0), "cinema_step_head: bad prepare arguments");
     CINEMA_REQUIRE(class_w == nullptr || (voxel && labels && n_cls >= 1), "cinema_step_head: class_w needs the label source");
@@ -800,7 +813,7 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
     a.g_pr = (int)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
     a.pr = StepPrepareArgs{dcoords, (long)n_dcoords, sums, voxel, idx, labels, (long)V, (long)N, n_cls, class_w, scratch};
   }
-  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nm + a.g_pr)), dim3(256), 0,
+  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nr + a.g_nm + a.g_pr)), dim3(256), 0,
                      (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;

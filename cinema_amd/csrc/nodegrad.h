@@ -16,6 +16,8 @@
 //   wt     bf16 [Npad/16][32][16]   interpolation weights, per 16-row block, slot-major (MFMA operand order)
 //   wrow   bf16 [Npad][32]          the same weights row-major; axt int32 [Npad][3][4]: the rows' interpolation axes
 //   T      bf16 [Rp][LP]            node rows of the table (+ the subject's conditions), Rp = S*32 rounded up to 128
+//   Tc     bf16 [Rp][LP]            the same rows minus the subject's mean over its nodes (noderows_device.h); T and Tc sit
+//                                   right behind offs, so their places depend on S only (cinema_step_head writes them)
 //   Up     bf16 [S*32][F]           centred projections U', F = n_mod * 2 * HP
 //   Vp     bf16 [S*32][16]          the same through final_linear.weight[:, H:]
 //   dU     bf16 [Rp][F], dUo16 bf16 [Rp][16], dUo32 fp32 [Rp][16]
@@ -31,10 +33,14 @@ struct NgPlan {
   long S, Npad, Rp;
   int n_mod, F, nparts, ncg, HP, LP;
   int layer_of[CINEMA_MAX_LAYERS];
-  size_t offs, wt, wrow, axt, T, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
+  size_t offs, T, Tc, wt, wrow, axt, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
 };
 bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz);
 NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad);
+
+// T and Tc from the latent table in its API layout (a launch of its own; the step head has the same body as a block range)
+int ng_launch_rows(const cinema_siren_desc *d, void *work, const float *latents, const float *cond_subject, int64_t S, int C,
+                   int lx, int ly, int lz, int cond_dims, hipStream_t s);
 
 // X -> dU, dUo, dcn (one launch).  gbuf: the backward scratch tensors (ds / dt slots, dOut16 in the last slot).
 int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, const void *gbuf, const float *coords_t,

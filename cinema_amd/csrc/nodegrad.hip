@@ -10,12 +10,16 @@
 namespace {
 
 #include "k1_device.h"
-#include "node_device.h"
+#include "noderows_device.h"
 #include "step_device.h"
 #include "dw_device.h"
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 cvt4(const f32x4 &v) {
+  bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  return o;
+}
 
 // ---- interpolation weight of one grid node as a function of the registered coordinate, and its derivative ----
 __device__ __forceinline__ float axis_w(const Axis &a, int i) {
@@ -71,16 +75,16 @@ struct NgWeightArgs {
   int32_t *offs; int nblk;       // the workgroup behind the nblk row blocks writes offs[0..S]: first row of every subject
   bf16_t *wrow; int32_t *axt;    // the same weights row-major [Npad][32]; interpolation axes [Npad][8 words]
 };
-__global__ __launch_bounds__(512) void k_ng_weights(NgWeightArgs a) {
-  __shared__ float ct[16][4];
+#define NG_WB 4                   // 16-row blocks per workgroup: one round of dependent loads (idx -> embed) serves 64 rows
+__device__ __forceinline__ void ng_weights_body(const NgWeightArgs &a, const long wg, float (*ct)[4]) {
   const int tid = threadIdx.x;
-  const long blk = blockIdx.x;
-  if (blk >= a.nblk) {
+  const long blk0 = wg * NG_WB;
+  if (blk0 >= a.nblk) {
     for (long t = tid; t <= a.S; t += 512) a.offs[t] = ng_lower(a.idx, a.N, t, a.S);
     return;
   }
-  if (tid < 16) {
-    const long n = blk * 16 + tid;
+  if (tid < 16 * NG_WB) {
+    const long n = blk0 * 16 + tid;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, ok = 0.f;
     if (n < a.N) {
       const float cx = a.coords[n * 3], cy = a.coords[n * 3 + 1], cz = a.coords[n * 3 + 2];
@@ -102,109 +106,144 @@ __global__ __launch_bounds__(512) void k_ng_weights(NgWeightArgs a) {
   }
   __syncthreads();
   const int slot = tid >> 4, i = tid & 15;
-  float w = 0.f;
-  if (ct[i][3] != 0.f) w = slot == NG_ONE_SLOT ? 1.f : slot_weight(ct[i][0], ct[i][1], ct[i][2], a.lx, a.ly, a.lz, slot);
-  a.wt[(blk * NG_SLOTS + slot) * 16 + i] = (bf16_t)w;
-  a.wrow[(blk * 16 + i) * NG_SLOTS + slot] = (bf16_t)w;
-  if (tid < 48) {        // (row, coordinate column): column 0 walks lz, 1 ly, 2 lx
+#pragma unroll
+  for (int q = 0; q < NG_WB; ++q) {
+    const long blk = blk0 + q;
+    if (blk >= a.nblk) break;
+    const int r = 16 * q + i;
+    float w = 0.f;
+    if (ct[r][3] != 0.f) w = slot == NG_ONE_SLOT ? 1.f : slot_weight(ct[r][0], ct[r][1], ct[r][2], a.lx, a.ly, a.lz, slot);
+    a.wt[(blk * NG_SLOTS + slot) * 16 + i] = (bf16_t)w;
+    a.wrow[(blk * 16 + i) * NG_SLOTS + slot] = (bf16_t)w;
+  }
+  if (tid < 48 * NG_WB) {  // (row, coordinate column): column 0 walks lz, 1 ly, 2 lx
     const int r = tid / 3, ax = tid - 3 * r;
-    const Axis q = axis_nodes(ct[r][ax], ax == 0 ? a.lz : (ax == 1 ? a.ly : a.lx));
-    int32_t *o = a.axt + (blk * 16 + r) * 8 + 2 * ax;      // {i0 | i1 << 8 | (clip inactive) << 16, w0}; words 6, 7 unused
-    o[0] = q.i0 | (q.i1 << 8) | (q.dmul != 0.f ? 1 << 16 : 0);
-    o[1] = __float_as_int(q.w0);
-    if (ax == 0) { o[6] = 0; o[7] = 0; }
+    if (blk0 * 16 + r < (long)a.nblk * 16) {
+      const Axis q = axis_nodes(ct[r][ax], ax == 0 ? a.lz : (ax == 1 ? a.ly : a.lx));
+      int32_t *o = a.axt + (blk0 * 16 + r) * 8 + 2 * ax;    // {i0 | i1 << 8 | (clip inactive) << 16, w0}; words 6, 7 unused
+      o[0] = q.i0 | (q.i1 << 8) | (q.dmul != 0.f ? 1 << 16 : 0);
+      o[1] = __float_as_int(q.w0);
+      if (ax == 0) { o[6] = 0; o[7] = 0; }
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_ng_rows(NodeRowArgs a) { node_rows_body(a, blockIdx.x, gridDim.x); }
-
 // ----------------------------------------------------------------------------------------
-// U'[s][slot][f] = sum_c Wl[f][c] * (table[s][c][slot] - mean_slot table[s][c][.])   and V' through final_linear[:, H:].
-// The mean over the G nodes is taken out in fp32 BEFORE the rows are rounded to bf16: d coords only sees differences
-// between the nodes of a cell (the derivative weights of a sample sum to zero), so the rounding error must scale with
-// the spread of a subject's nodes, not with their common part.  Conditions are per subject: their centred rows are zero.
-// Workgroup (4 waves) = (subject, modulated layer, quarter of the 2 HP features); C[m = feature][n = slot].
+// U'[s][slot][f] = sum_c Wl[f][c] * Tc[s][slot][c]   and V' through final_linear[:, H:]   (Tc: noderows_device.h).
+// Workgroup (8 waves) = (4 subjects, modulated layer, eighth of the 2 HP features); C[m = feature][n = slot].  The 128
+// centred rows are one contiguous piece of Tc: copied into a swizzled LDS image; a wave requests all weight fragments of
+// a 16-feature tile before its first product (one L2 round trip per tile) and every fragment serves the eight products of
+// its four subjects.  (One subject per workgroup re-read the weights S times, and centring the rows in here -- 24
+// workgroups per subject, strided fp32 loads of the API layout -- cost 17 us at cfg-D.)
 // ----------------------------------------------------------------------------------------
 struct NgProjArgs {
-  const float *latents; long S; int C, G, LP, HP, F, n_mod;
+  const bf16_t *Tc; long S; int LP, HP, F, n_mod;
   const bf16_t *packed; long pk_wls[CINEMA_MAX_LAYERS], pk_wlt[CINEMA_MAX_LAYERS]; long pk_wf;
   int layer_of[CINEMA_MAX_LAYERS];
   bf16_t *Up, *Vp;
 };
-#define NG_PROJ_Q 4
-__global__ __launch_bounds__(256) void k_ng_project(NgProjArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char *tc = (lds_char *)smem;                       // [32 slots][LP] bf16, 16-B chunk c of row r at c ^ (r & 7)
+#define NG_PROJ_Q 8                               // feature parts per (subject group, layer)
+#define NG_PROJ_SG 4                              // subjects per workgroup: every weight fragment serves 8 products
+__device__ __forceinline__ void ng_proj_tile(const NgProjArgs &a, const lds_char *tc, const bf16_t *wrow, int ksteps, int i, int g,
+                                             f32x4 (&acc)[NG_PROJ_SG][2]) {
+  const int rowb = a.LP * 2, img = NG_SLOTS * rowb;
+  for (int k0 = 0; k0 < ksteps; k0 += 8) {
+    bf16x8 af[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) af[u] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * (k0 + u < ksteps ? k0 + u : ksteps - 1));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u < ksteps) {
+#pragma unroll
+        for (int q = 0; q < NG_PROJ_SG; ++q)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int r = 16 * nt + i;
+            const bf16x8 bfr = *(const LDS_AS bf16x8 *)(tc + q * img + r * rowb + (((4 * (k0 + u) + g) ^ (r & 7)) << 4));
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], bfr, acc[q][nt], 0, 0, 0);
+          }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void ng_project_body(const NgProjArgs &a, int b, lds_char *tc, int skip) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  int b = blockIdx.x;
-  const int quarter = b % NG_PROJ_Q; b /= NG_PROJ_Q;
+  const int part = b % NG_PROJ_Q; b /= NG_PROJ_Q;
   const int jm = b % a.n_mod;
-  const long s = b / a.n_mod;
+  const long s0 = (long)(b / a.n_mod) * NG_PROJ_SG;
   const int rowb = a.LP * 2;
-  for (int c = tid; c < a.LP; c += 256) {
-    float v[NG_SLOTS];
-    float mean = 0.f;
+  {
+    // rows s0 * 32 .. + 127 of Tc (rows behind S * 32 exist and are zero: Rp is a multiple of 128)
+    const int cpr = a.LP >> 3, total = NG_PROJ_SG * NG_SLOTS * cpr;
+    const bf16_t *src = a.Tc + s0 * NG_SLOTS * a.LP;
+    for (int e0 = tid; e0 < total; e0 += 512 * 8) {
+      u32x4 v[8];
 #pragma unroll
-    for (int k = 0; k < NG_SLOTS; ++k) {
-      v[k] = (c < a.C && k < a.G) ? a.latents[(s * a.C + c) * a.G + k] : 0.f;
-      mean += v[k];
-    }
-    mean /= (float)a.G;
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 512 * u;
+        v[u] = *reinterpret_cast<const u32x4 *>(src + (long)(e < total ? e : tid) * 8);
+      }
 #pragma unroll
-    for (int k = 0; k < NG_SLOTS; ++k) {
-      const float x = (c < a.C && k < a.G) ? v[k] - mean : 0.f;
-      *(LDS_AS bf16_t *)(tc + k * rowb + ((((c >> 3) ^ (k & 7)) << 4) | ((c & 7) * 2))) = (bf16_t)x;
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 512 * u;
+        if (e < total) {
+          const int r = e / cpr, j = e - r * cpr;           // r = 32 q + slot: the images of the four subjects are adjacent
+          *(LDS_AS u32x4 *)(tc + r * rowb + ((j ^ (r & 7)) << 4)) = v[u];
+        }
+      }
     }
   }
   __syncthreads();
   const int ksteps = a.LP >> 5;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int layer = a.layer_of[jm];
-  // features of this workgroup: [quarter * HP/2, (quarter + 1) * HP/2) of the 2 HP (scale half, then shift half)
-  const int fq = a.HP >> 1, nmt = fq >> 4;                // m-tiles of 16 features in the quarter
-  for (int mt = wave; mt < nmt; mt += 4) {
-    const int f = quarter * fq + mt * 16;                 // first feature of the tile in [0, 2 HP)
+  // 16-feature tiles of this workgroup: its share of the 2 HP / 16 (scale half, then shift half)
+  const int total_mt = a.HP >> 3, per = (total_mt + NG_PROJ_Q - 1) / NG_PROJ_Q;
+  const int mt_end = min(total_mt, (part + 1) * per);
+  for (int mt = part * per + wave; mt < mt_end; mt += 8) {
+    const int f = mt * 16;                                // first feature of the tile in [0, 2 HP)
     const int half = f >= a.HP ? 1 : 0, hf = f - half * a.HP;
     const bf16_t *wrow = a.packed + (half ? a.pk_wlt[layer] : a.pk_wls[layer]) + (long)(hf + i) * a.LP + 8 * g;
-    f32x4 acc[2] = {zero4, zero4};
-#pragma unroll 4
-    for (int kk = 0; kk < ksteps; ++kk) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8 *>(wrow + 32 * kk);
+    f32x4 acc[NG_PROJ_SG][2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int r = 16 * nt + i;
-        const bf16x8 bfr = *(const LDS_AS bf16x8 *)(tc + r * rowb + (((4 * kk + g) ^ (r & 7)) << 4));
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nt], 0, 0, 0);
-      }
-    }
+    for (int q = 0; q < NG_PROJ_SG; ++q) { acc[q][0] = zero4; acc[q][1] = zero4; }
+    if (!(skip & 16)) ng_proj_tile(a, tc, wrow, ksteps, i, g, acc);
     // lane (i = slot, g): features f + 4g .. + 3
+    if (!(skip & 32))
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      bf16x4 o = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
-      *reinterpret_cast<bf16x4 *>(a.Up + (s * NG_SLOTS + 16 * nt + i) * a.F + (long)jm * 2 * a.HP + f + 4 * g) = o;
-    }
+    for (int q = 0; q < NG_PROJ_SG; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        if (s0 + q < a.S)
+          *reinterpret_cast<bf16x4 *>(a.Up + ((s0 + q) * NG_SLOTS + 16 * nt + i) * a.F + (long)jm * 2 * a.HP + f + 4 * g) = cvt4(acc[q][nt]);
   }
-  if (jm == 0 && quarter == 0 && wave == 3) {
+  if (jm == 0 && part == NG_PROJ_Q - 1 && wave == 7) {
     // V'[slot][o] = sum_c Wf[o][H + c] * Tc[slot][c]   (padded [16][HP + LP] copy of final_linear)
     const bf16_t *wrow = a.packed + a.pk_wf + (long)i * (a.HP + a.LP) + a.HP + 8 * g;
-    f32x4 acc[2] = {zero4, zero4};
-    for (int kk = 0; kk < ksteps; ++kk) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8 *>(wrow + 32 * kk);
+    f32x4 acc[NG_PROJ_SG][2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int r = 16 * nt + i;
-        const bf16x8 bfr = *(const LDS_AS bf16x8 *)(tc + r * rowb + (((4 * kk + g) ^ (r & 7)) << 4));
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nt], 0, 0, 0);
-      }
-    }
+    for (int q = 0; q < NG_PROJ_SG; ++q) { acc[q][0] = zero4; acc[q][1] = zero4; }
+    ng_proj_tile(a, tc, wrow, ksteps, i, g, acc);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      bf16x4 o = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
-      *reinterpret_cast<bf16x4 *>(a.Vp + (s * NG_SLOTS + 16 * nt + i) * 16 + 4 * g) = o;
-    }
+    for (int q = 0; q < NG_PROJ_SG; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        if (s0 + q < a.S)
+          *reinterpret_cast<bf16x4 *>(a.Vp + ((s0 + q) * NG_SLOTS + 16 * nt + i) * 16 + 4 * g) = cvt4(acc[q][nt]);
   }
+}
+
+// everything the node-space backward needs before it can start (behind the node rows), in ONE launch (block ranges)
+__global__ __launch_bounds__(256) void k_ng_rows(NodeRowsCArgs a) { node_rows_centred_body(a, blockIdx.x); }
+struct NgPrepArgs { NgWeightArgs w; NgProjArgs p; int g_w, skip; };
+__global__ __launch_bounds__(512) void k_ng_prepare(NgPrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int b = blockIdx.x;
+  if (b < a.g_w) { if (!(a.skip & 1)) ng_weights_body(a.w, b, (float (*)[4])smem_raw); return; }
+  b -= a.g_w;
+  if (!(a.skip & 4)) ng_project_body(a.p, b, (lds_char *)smem_raw, a.skip);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -226,10 +265,6 @@ struct NgGradArgs {
   int dbg;      // developer ablations (cinema_debug_node_grad): 1 = no exchange / d coords, 2 = no dU products, 4 = no dwn products
 };
 
-__device__ __forceinline__ bf16x4 cvt4(const f32x4 &v) {
-  bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-  return o;
-}
 __device__ __forceinline__ f32x4 mfma16(const bf16x4 &a, const bf16x4 &b, const f32x4 &c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
 }
@@ -583,7 +618,9 @@ __device__ __forceinline__ void ng_tail_table(const NgTailArgs &a, int vb) {
   const long s = vb / a.tab_cs;
   const int c0 = (vb - (int)s * a.tab_cs) * 64;
   const int tid = threadIdx.x;
-  for (int q = tid; q < NG_SLOTS * 64; q += 256) {
+#pragma unroll
+  for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) {      // unrolled: the loads of all slots are in flight together
+    const int q = tid + 256 * u;
     const int k = q >> 6, cc = q & 63;
     float v = 0.f;
     if (k < a.G && c0 + cc < a.LP)
@@ -691,10 +728,11 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
   p.offs = take((size_t)(S + 1) * 4);
+  p.T = take((size_t)p.Rp * d->LP * 2);       // T and Tc first: their places do not depend on Npad (the step head writes them)
+  p.Tc = take((size_t)p.Rp * d->LP * 2);
   p.wt = take((size_t)(Npad / 16) * NG_SLOTS * 16 * 2);
   p.wrow = take((size_t)Npad * NG_SLOTS * 2 + 1024);
   p.axt = take((size_t)Npad * 8 * 4 + 1024);
-  p.T = take((size_t)p.Rp * d->LP * 2);
   p.Up = take((size_t)p.Rp * p.F * 2);
   p.Vp = take((size_t)p.Rp * 16 * 2);
   p.dU = take((size_t)p.Rp * p.F * 2);
@@ -718,10 +756,22 @@ extern "C" int cinema_nodegrad_eligible(const cinema_siren_desc *d, int32_t lx, 
   return d != nullptr && ng_eligible(d, lx, ly, lz) ? 1 : 0;
 }
 
+// node rows T and Tc of the work buffer (cinema_step_head writes them itself when it is given the buffer)
+int ng_launch_rows(const cinema_siren_desc *d, void *work, const float *latents, const float *cond_subject, int64_t S, int C,
+                   int lx, int ly, int lz, int cond_dims, hipStream_t s) {
+  CINEMA_REQUIRE(d->LP % 32 == 0, "node rows: padded latent width %d is not a multiple of 32", d->LP);
+  const NgPlan p = ng_plan(d, S, 128);                   // the places of T and Tc do not depend on Npad
+  NodeRowsCArgs r = {latents, cond_subject, (long)S, C, lx * ly * lz, cond_dims, d->LP, (bf16_t *)((char *)work + p.T),
+                     (bf16_t *)((char *)work + p.Tc)};
+  hipLaunchKernelGGL(k_ng_rows, dim3((unsigned)(S * (d->LP / 32))), dim3(256), 0, s, r);
+  CINEMA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *packed, const float *coords, const int32_t *idx,
                                        const float *embed, int32_t tf_dim, const float *latents, const float *cond_subject,
                                        int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz,
-                                       int32_t cond_dims, void *work, void *stream) {
+                                       int32_t cond_dims, void *work, int32_t flags, void *stream) {
   CINEMA_REQUIRE(d && packed && coords && idx && latents && work, "cinema_nodegrad_prepare: null argument");
   CINEMA_REQUIRE(ng_eligible(d, lx, ly, lz), "cinema_nodegrad_prepare: needs a bf16 stack on the activation-stationary path with a "
                  "modulated layer and a latent grid of at most %d nodes (got %d x %d x %d)", NG_ONE_SLOT - 1, lx, ly, lz);
@@ -733,28 +783,30 @@ extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *p
   const NgPlan p = ng_plan(d, S, Npad);
   char *w = (char *)work;
   const int G = lx * ly * lz;
-  NgWeightArgs wa = {coords, idx, embed, tf_dim, (long)N, (long)S, lx, ly, lz, (bf16_t *)(w + p.wt), (int32_t *)(w + p.offs),
-                     (int)(Npad / 16), (bf16_t *)(w + p.wrow), (int32_t *)(w + p.axt)};
-  hipLaunchKernelGGL(k_ng_weights, dim3((unsigned)(Npad / 16 + 1)), dim3(512), 0, s, wa);
-  CINEMA_CHECK_HIP(hipGetLastError());
-  NodeRowArgs r = {latents, cond_subject, (long)S, C, G, cond_dims, d->LP, (bf16_t *)(w + p.T)};
-  const long total = (long)S * NODE_SLOTS * (d->LP / 8);
-  hipLaunchKernelGGL(k_ng_rows, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, r);
-  CINEMA_CHECK_HIP(hipGetLastError());
-  NgProjArgs pa = {};
-  pa.latents = latents; pa.S = (long)S; pa.C = C; pa.G = G; pa.LP = d->LP; pa.HP = d->HP; pa.F = p.F; pa.n_mod = p.n_mod;
-  pa.packed = (const bf16_t *)packed; pa.pk_wf = d->pk_wf;
-  for (int j = 0; j < p.n_mod; ++j) {
-    pa.layer_of[j] = p.layer_of[j];
-    pa.pk_wls[p.layer_of[j]] = d->pk_wls[p.layer_of[j]];
-    pa.pk_wlt[p.layer_of[j]] = d->pk_wlt[p.layer_of[j]];
+  if (!(flags & 1)) {                          // node rows not written by the step head: a launch of their own
+    const int rc = ng_launch_rows(d, work, latents, cond_subject, S, C, lx, ly, lz, cond_dims, s);
+    if (rc) return rc;
   }
-  pa.Up = (bf16_t *)(w + p.Up); pa.Vp = (bf16_t *)(w + p.Vp);
-  const int smem = NG_SLOTS * d->LP * 2;
-  CINEMA_REQUIRE(smem <= 64 * 1024, "cinema_nodegrad_prepare: lat_size %d too wide for the LDS staging", d->lat);
-  CINEMA_REQUIRE((long)S * p.n_mod * NG_PROJ_Q < (1L << 30), "cinema_nodegrad_prepare: too many subjects");
-  CINEMA_SMEM_ATTR(k_ng_project, smem);
-  hipLaunchKernelGGL(k_ng_project, dim3((unsigned)(S * p.n_mod * NG_PROJ_Q)), dim3(256), smem, s, pa);
+  NgPrepArgs pa = {};
+  pa.w = NgWeightArgs{coords, idx, embed, tf_dim, (long)N, (long)S, lx, ly, lz, (bf16_t *)(w + p.wt), (int32_t *)(w + p.offs),
+                      (int)(Npad / 16), (bf16_t *)(w + p.wrow), (int32_t *)(w + p.axt)};
+  pa.g_w = (int)((Npad / 16 + NG_WB - 1) / NG_WB + 1);
+  pa.p.Tc = (const bf16_t *)(w + p.Tc); pa.p.S = (long)S; pa.p.LP = d->LP; pa.p.HP = d->HP; pa.p.F = p.F; pa.p.n_mod = p.n_mod;
+  pa.p.packed = (const bf16_t *)packed; pa.p.pk_wf = d->pk_wf;
+  for (int j = 0; j < p.n_mod; ++j) {
+    pa.p.layer_of[j] = p.layer_of[j];
+    pa.p.pk_wls[p.layer_of[j]] = d->pk_wls[p.layer_of[j]];
+    pa.p.pk_wlt[p.layer_of[j]] = d->pk_wlt[p.layer_of[j]];
+  }
+  pa.p.Up = (bf16_t *)(w + p.Up); pa.p.Vp = (bf16_t *)(w + p.Vp);
+  static const int prep_skip = getenv("CINEMA_NG_PREP_SKIP") ? atoi(getenv("CINEMA_NG_PREP_SKIP")) : 0;   // developer timing only
+  pa.skip = prep_skip;
+  const int smem = std::max(NG_PROJ_SG * NG_SLOTS * d->LP * 2, 16 * NG_WB * 16);
+  CINEMA_REQUIRE(smem <= 160 * 1024, "cinema_nodegrad_prepare: lat_size %d too wide for the LDS staging", d->lat);
+  const long g_p = (long)((S + NG_PROJ_SG - 1) / NG_PROJ_SG) * p.n_mod * NG_PROJ_Q;
+  CINEMA_REQUIRE(pa.g_w + g_p < (1L << 30), "cinema_nodegrad_prepare: too many subjects");
+  CINEMA_SMEM_ATTR(k_ng_prepare, smem);
+  hipLaunchKernelGGL(k_ng_prepare, dim3((unsigned)(pa.g_w + g_p)), dim3(512), smem, s, pa);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }

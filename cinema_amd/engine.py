@@ -266,16 +266,18 @@ def nodegrad_eligible(eng: "SirenEngine", latents_shape) -> bool:
 
 
 def nodegrad_prepare(eng: "SirenEngine", ng: NodeGrad, coords: torch.Tensor, idx: torch.Tensor, table: torch.Tensor,
-                     cond_subject: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int):
+                     cond_subject: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, rows_ready: bool = False):
     """Interpolation weights of the batch + node rows / centred node projections of the current table (after the packed
-    weight copies were refreshed: step_head, or eng.pack(2 | 8))."""
+    weight copies were refreshed: step_head, or eng.pack(2 | 8)).  rows_ready: step_head(..., ng=ng) of this step wrote
+    the node rows already."""
     S, Cc, lx, ly, lz = table.shape
     cond_dims = 0 if cond_subject is None else cond_subject.shape[1]
     npad = round_up(n, ROW_ALIGN)
     ng.ensure(eng, S, npad)
     check(eng.lib.cinema_nodegrad_prepare(C.byref(eng.desc), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
                                           0 if tfs is None else tfs.shape[1], ptr(table), ptr(cond_subject) if cond_dims else None,
-                                          n, npad, S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), eng.stream()),
+                                          n, npad, S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), 1 if rows_ready else 0,
+                                          eng.stream()),
           "cinema_nodegrad_prepare")
 
 
@@ -410,10 +412,12 @@ def cond_table_grad(idx_sorted: torch.Tensor, dcond: torch.Tensor, n: int, out: 
 
 def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: torch.Tensor, latents: torch.Tensor,
               cond: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, prepare: Optional[dict] = None,
-              shadow: bool = True, cond_by_subject: bool = False):
+              shadow: bool = True, cond_by_subject: bool = False, ng: Optional["NodeGrad"] = None):
     """eng.pack() + k1_forward_sorted (+ k1_shadow, + step_prepare) in ONE launch (cinema_step_head); the caller
     checked k1_sorted_eligible and eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use).
-    prepare: dict(dcoords, sums, n_cls, class_w, voxel, labels, V, scratch) or None."""
+    prepare: dict(dcoords, sums, n_cls, class_w, voxel, labels, V, scratch) or None.
+    ng: work buffer of the node-space backward -- its node rows are written in the same launch (nodegrad_prepare is then
+    called with rows_ready=True)."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents.shape
     cond_dims = 0 if cond is None else cond.shape[1]
@@ -424,12 +428,14 @@ def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: t
         if st.shadow is None or st.shadow.numel() != S * G * Cc:
             st.shadow = torch.empty(S, G, Cc, device=eng.device, dtype=torch.float32)
         sh = st.shadow
+    if ng is not None:
+        ng.ensure(eng, S, npad)
     p = prepare or {}
     dco = p.get("dcoords")
     check(lib.cinema_step_head(C.byref(d), ptr(eng.flat), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
                                0 if tfs is None else tfs.shape[1], ptr(latents), ptr(cond) if cond_dims else None, n, npad,
                                S, Cc, lx, ly, lz, cond_dims, 1 if cond_by_subject else 0, ptr(ws.coords_t), ptr(ws.lat), ptr(sh),
-                               ptr(dco),
+                               None if ng is None else ptr(ng.work), ptr(dco),
                                0 if dco is None else dco.numel(), ptr(p.get("sums")), ptr(p.get("voxel")), ptr(p.get("labels")),
                                int(p.get("V", 0)), int(p.get("n_cls", 0)), ptr(p.get("class_w")), ptr(p.get("scratch")),
                                eng.stream()), "cinema_step_head")

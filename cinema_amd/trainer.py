@@ -227,7 +227,8 @@ class HotPathTrainer:
             # everything in front of the forward as ONE launch (cinema_step_head): no second stream, no join
             E.step_head(eng, self.k1, coords, subj, table, cond_table, tfs, n, cond_by_subject=True,
                         prepare=dict(dcoords=ws.dcoords, sums=self.sums, n_cls=self.n_cls, class_w=self.class_w if use_cw else None,
-                                     voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch), shadow=not use_ng)
+                                     voxel=voxel, labels=st.labels, V=st.V, scratch=self.prep_scratch), shadow=not use_ng,
+                        ng=self.ng if use_ng else None)
         elif self.side is not None:
             side = self.side
             side.wait_stream(main)                  # the previous step's optimiser wrote the parameters
@@ -242,20 +243,20 @@ class HotPathTrainer:
             k1_fwd()
             backward_only_prep()
         norm = self._union_normaliser(n, use_cw, joined)      # rank of several: started here, hidden under the forward
-        ng_on_side = use_ng and one_head and self.side is not None
+        ng_on_side = use_ng and one_head and self.side is not None and os.environ.get("CINEMA_NG_SIDE", "0") == "1"
         if ng_on_side:
             # node tables of the backward (interpolation weights, node rows, centred projections): they need the packed
             # weights of the head launch and nothing of the forward -> beside it, joined before the backward
             self.ev_head.record(main)
             self.side.wait_event(self.ev_head)
             with torch.cuda.stream(self.side):
-                E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)
+                E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n, rows_ready=True)
                 self.ev_prep.record(self.side)
+        elif use_ng:
+            E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n, rows_ready=one_head)   # one launch, in line
         eng.forward(n)
         if not joined:
             main.wait_event(self.ev_prep)
-        if use_ng and not ng_on_side:
-            E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,
                       float(self.seg_weight) ** 2, ws.dout, self.sums, voxel=voxel, subj=subj, intens=st.intens,
                       labels=st.labels, voxels_per_subject=st.V, prepared=True, norm=None if norm is None else norm.wait())

@@ -218,7 +218,9 @@ int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, co
  * (sums != NULL; subj = idx) as block ranges of one kernel -- independent work that separate launches would run one
  * after the other on one stream, or with a 6-10 us join on two.  bf16 stacks on the activation-stationary path only
  * (hidden <= 512, `pk_fs >= 0` after planning) and the shapes cinema_affine_trilerp_fwd_sorted takes; LP and the
- * precision come from the descriptor.  Same bits as the separate calls. */
+ * precision come from the descriptor.  Same bits as the separate calls.
+ * node_work != NULL (the work buffer of the node-space backward, below): the node rows of the current table are written
+ * too, as one more block range -- cinema_nodegrad_prepare is then called with flags & 1 and skips that launch. */
 /* Gradient of the per-subject condition table from the per-sample rows dcond [N x cond_dims] the backward calls leave, for
  * a batch sorted by subject: dtable[s] = sum of the rows with idx == s (what autograd's index_add does for
  * conditions[idcs_df], build_atlas.py:74-75).  One workgroup per subject, ranges by binary search, deterministic. */
@@ -227,7 +229,8 @@ int cinema_cond_table_bwd(const int32_t *idx_sorted, const float *dcond, int64_t
 int cinema_step_head(const cinema_siren_desc *d /* host */, const float *params, void *packed, const float *coords,
                      const int32_t *idx, const float *embed, int32_t tf_dim, const float *latents, const float *cond,
                      int64_t N, int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
-                     int32_t cond_by_subject, float *coords_t, void *lat_out, float *shadow, float *dcoords, int64_t n_dcoords, float *sums,
+                     int32_t cond_by_subject, float *coords_t, void *lat_out, float *shadow, void *node_work, float *dcoords,
+                     int64_t n_dcoords, float *sums,
                      const int64_t *voxel, const uint8_t *labels, int64_t V, int32_t n_cls, const float *class_w,
                      float *scratch, void *stream);
 
@@ -348,6 +351,7 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
  *   cinema_nodegrad_prepare: per step, after the weights were packed (cinema_siren_pack_part with bits 2 | 8, or
  *     cinema_step_head) -- interpolation weights of the batch, node rows and centred node projections of the current
  *     table (`latents` (S, C, lx, ly, lz): the table K1 interpolates; cond_subject [S x cond_dims] or NULL).
+ *     flags & 1: cinema_step_head already wrote the node rows of this table into `work` (one launch instead of two).
  *   cinema_siren_backward_nodegrad: flags as cinema_siren_backward (SKIP_WEIGHT_GRADS, GRADS_CLEARED, DCOORDS_CLEARED,
  *     WEIGHTS_FIRST / DLAT_ONLY: the first call leaves grad_params complete, the second one the table-side gradients).
  *     Outputs (overwritten): grad_params, dlatents (S, C, lx, ly, lz), dembed [S x tf_dim] or NULL, dcond [S x cond_dims]
@@ -358,7 +362,7 @@ int64_t cinema_nodegrad_work_bytes(const cinema_siren_desc *d /* host */, int64_
 int cinema_nodegrad_prepare(const cinema_siren_desc *d /* host */, const void *packed, const float *coords, const int32_t *idx,
                             const float *embed, int32_t tf_dim, const float *latents, const float *cond_subject, int64_t N,
                             int64_t Npad, int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t cond_dims,
-                            void *work, void *stream);
+                            void *work, int32_t flags, void *stream);
 int cinema_siren_backward_nodegrad(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
                                    const float *coords_t, const void *saved, const float *dout, int64_t N, int64_t Npad,
                                    void *gbuf, float *grad_params, float *dcoords, int32_t flags, const float *coords,

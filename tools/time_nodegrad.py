@@ -38,6 +38,19 @@ def run(dbg):
                                           dbg, eng.stream()), "debug_node_grad")
 
 
+if os.environ.get("PREP"):
+    for _ in range(3):
+        E.nodegrad_prepare(eng, ng, coords, idx, latents, None, tfs, N)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        E.nodegrad_prepare(eng, ng, coords, idx, latents, None, tfs, N)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"k_ng_prepare skip={os.environ.get('CINEMA_NG_PREP_SKIP', '0')}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us", flush=True)
+    sys.exit(0)
+
 for dbg in [int(x) for x in os.environ.get("DBG", "0,1,2,4,6,7").split(",")]:
     for _ in range(3):
         run(dbg)
