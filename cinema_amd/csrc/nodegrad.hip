@@ -593,7 +593,7 @@ __global__ __launch_bounds__(512, 4) void k_node_grad(NgGradArgs a) {
 // tail of the backward: block ranges of one launch
 // ----------------------------------------------------------------------------------------
 struct NgTailArgs {
-  Dw256Args red; int g_red;
+  Dw256Args red; int g_red, skip;
   // linear_lats.bias gradients: column sums of the constant-1 slot rows of dU
   const bf16_t *dU; float *gp; long off_bl[CINEMA_MAX_LAYERS]; int layer_of[CINEMA_MAX_LAYERS]; int n_mod, H, HP, F, g_bias;
   // d table / d cond from the dT parts
@@ -602,14 +602,35 @@ struct NgTailArgs {
   const float *coords, *dcoords, *dcn, *embed; float *dembed; const int32_t *offs; long N, Npad, S; int tf_dim, nparts, g_tf;
 };
 
+// workgroup = 32 columns of dU x 8 groups of subjects: a thread requests its subjects' rows eight at a time (one thread
+// per column walked S dependent-latency loads in a row and paced the whole launch)
 __device__ __forceinline__ void ng_tail_bias(const NgTailArgs &a, int vb) {
-  const int col = vb * 256 + threadIdx.x;             // column of dU: (jm, half, feature)
-  if (col >= a.F) return;
-  const int t = col / a.HP, f = col - t * a.HP;
-  if (f >= a.H) return;
+  __shared__ float part[8][33];
+  const int tid = threadIdx.x, cl = tid & 31, sg = tid >> 5;
+  const int col = vb * 32 + cl;                       // column of dU: (jm, half, feature)
   float acc = 0.f;
-  for (long s = 0; s < a.S; ++s) acc += (float)a.dU[(s * NG_SLOTS + NG_ONE_SLOT) * a.F + col];
-  a.gp[a.off_bl[a.layer_of[t >> 1]] + (long)(t & 1) * a.H + f] = acc;
+  if (col < a.F) {
+    for (long s0 = sg; s0 < a.S; s0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long s = s0 + 8 * u;
+        v[u] = (float)a.dU[((s < a.S ? s : a.S - 1) * NG_SLOTS + NG_ONE_SLOT) * a.F + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += s0 + 8 * u < a.S ? v[u] : 0.f;
+    }
+  }
+  part[sg][cl] = acc;
+  __syncthreads();
+  if (tid < 32 && col < a.F) {
+    const int t = col / a.HP, f = col - t * a.HP;
+    if (f >= a.H) return;
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r += part[g][cl];
+    a.gp[a.off_bl[a.layer_of[t >> 1]] + (long)(t & 1) * a.H + f] = r;
+  }
 }
 
 // workgroup = (subject, slice of 64 columns of the node rows): dlatents[s][c][k] = sum over the parts of dT[s*32 + k][c]
@@ -618,15 +639,27 @@ __device__ __forceinline__ void ng_tail_table(const NgTailArgs &a, int vb) {
   const long s = vb / a.tab_cs;
   const int c0 = (vb - (int)s * a.tab_cs) * 64;
   const int tid = threadIdx.x;
+  float acc[NG_SLOTS * 64 / 256];
 #pragma unroll
-  for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) {      // unrolled: the loads of all slots are in flight together
-    const int q = tid + 256 * u;
-    const int k = q >> 6, cc = q & 63;
-    float v = 0.f;
-    if (k < a.G && c0 + cc < a.LP)
-      for (int p = 0; p < a.nseg; ++p) v += a.dT[(long)p * a.part_stride + (s * NG_SLOTS + k) * a.LP + c0 + cc];
-    tile[k][cc] = v;
+  for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) acc[u] = 0.f;
+  const int cc = tid & 63, k0 = tid >> 6;                // rows k0 + 4 u; rows >= G of the parts are zero (never written)
+  const float *src = a.dT + (s * NG_SLOTS + k0) * a.LP + (c0 + cc < a.LP ? c0 + cc : 0);
+  for (int p = 0; p < a.nseg; p += 2) {                  // the loads of two parts (16) are in flight together
+    float v[2][NG_SLOTS * 64 / 256];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < NG_SLOTS * 64 / 256; ++u)
+        v[h][u] = src[(long)(p + h < a.nseg ? p + h : p) * a.part_stride + (long)4 * u * a.LP];
+#pragma unroll
+    for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) acc[u] += v[0][u];
+    if (p + 1 < a.nseg) {
+#pragma unroll
+      for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) acc[u] += v[1][u];
+    }
   }
+#pragma unroll
+  for (int u = 0; u < NG_SLOTS * 64 / 256; ++u) tile[k0 + 4 * u][cc] = (k0 + 4 * u < a.G && c0 + cc < a.LP) ? acc[u] : 0.f;
   __syncthreads();
   for (int q = tid; q < 64 * a.G; q += 256) {
     const int cc = q / a.G, k = q - cc * a.G;
@@ -649,21 +682,40 @@ __device__ __forceinline__ void ng_tail_tf(const NgTailArgs &a, int vb) {
   const long s = vb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rng[2] = {a.offs[s], a.offs[s + 1]};
+  float ev[12];                                           // requested now, used by thread 0 at the end
+#pragma unroll
+  for (int k = 0; k < 12; ++k) ev[k] = (tid == 0 && k < a.tf_dim) ? a.embed[s * a.tf_dim + k] : 0.f;
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-  for (int n = rng[0] + tid; n < rng[1]; n += 256) {
-    float d[3] = {a.dcoords[(long)n * 3], a.dcoords[(long)n * 3 + 1], a.dcoords[(long)n * 3 + 2]};
-    for (int p = 0; p < a.nparts; ++p) {
-      const f32x4 q = *reinterpret_cast<const f32x4 *>(a.dcn + ((long)p * a.Npad + n) * 4);
-      d[0] += q[0]; d[1] += q[1]; d[2] += q[2];
+  for (int n0 = rng[0] + tid; n0 < rng[1]; n0 += 512) {   // two rows per thread and pass: all their loads in flight together
+    float d[2][3], c[2][3];
+    f32x4 q[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long n = n0 + 256 * h < rng[1] ? n0 + 256 * h : n0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { d[h][r] = a.dcoords[n * 3 + r]; c[h][r] = a.coords[n * 3 + r]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[h][u] = *reinterpret_cast<const f32x4 *>(a.dcn + ((long)(u < a.nparts ? u : 0) * a.Npad + n) * 4);
     }
-    const float c[3] = {a.coords[(long)n * 3], a.coords[(long)n * 3 + 1], a.coords[(long)n * 3 + 2]};
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int h = 0; h < 2; ++h) {
+      const long n = n0 + 256 * h;
+      if (n >= rng[1]) break;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[r * 3 + j] += d[r] * c[j];
-      acc[9 + r] += d[r];
+      for (int u = 0; u < 8; ++u)
+        if (u < a.nparts) { d[h][0] += q[h][u][0]; d[h][1] += q[h][u][1]; d[h][2] += q[h][u][2]; }
+      for (int p = 8; p < a.nparts; ++p) {                 // more than eight parts (hidden > 512 or > 3 modulated layers)
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(a.dcn + ((long)p * a.Npad + n) * 4);
+        d[h][0] += x[0]; d[h][1] += x[1]; d[h][2] += x[2];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[r * 3 + j] += d[h][r] * c[h][j];
+        acc[9 + r] += d[h][r];
+      }
     }
   }
 #pragma unroll
@@ -683,7 +735,8 @@ __device__ __forceinline__ void ng_tail_tf(const NgTailArgs &a, int vb) {
       for (int j = 0; j < 3; ++j) G.m[r][j] = t[r * 3 + j];
       d[r] = t[9 + r];
     }
-    for (int k = 0; k < 12; ++k) e[k] = k < a.tf_dim ? a.embed[s * a.tf_dim + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) e[k] = ev[k];
     embed_grad(e, a.tf_dim, G, d, g);
     for (int k = 0; k < a.tf_dim; ++k) a.dembed[s * a.tf_dim + k] = g[k];
   }
@@ -691,13 +744,13 @@ __device__ __forceinline__ void ng_tail_tf(const NgTailArgs &a, int vb) {
 
 __global__ __launch_bounds__(256) void k_ng_tail(NgTailArgs a) {
   int b = blockIdx.x;
-  if (b < a.g_red) { dw256_reduce_body(a.red, b); return; }
-  b -= a.g_red;
-  if (b < a.g_tab) { ng_tail_table(a, b); return; }
-  b -= a.g_tab;
-  if (b < a.g_tf) { ng_tail_tf(a, b); return; }
+  if (b < a.g_tf) { if (!(a.skip & 4)) ng_tail_tf(a, b); return; }      // the longest chain of dependent steps first
   b -= a.g_tf;
-  ng_tail_bias(a, b);
+  if (b < a.g_red) { if (!(a.skip & 1)) dw256_reduce_body(a.red, b); return; }
+  b -= a.g_red;
+  if (b < a.g_tab) { if (!(a.skip & 2)) ng_tail_table(a, b); return; }
+  b -= a.g_tab;
+  if (!(a.skip & 8)) ng_tail_bias(a, b);
 }
 
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -852,7 +905,7 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   for (int j = 0; j < p.n_mod; ++j) a.layer_of[j] = p.layer_of[j];
   for (int i = 0; i < d->n_layers; ++i) a.off_bl[i] = d->off_bl[i];
   a.S = p.S; a.Npad = p.Npad; a.N = (long)t.N;
-  if (t.grad_params != nullptr) { a.gp = t.grad_params; a.g_bias = (p.F + 255) / 256; }
+  if (t.grad_params != nullptr) { a.gp = t.grad_params; a.g_bias = (p.F + 31) / 32; }
   if (t.dlatents != nullptr) {
     a.dT = (const float *)(w + p.dT); a.part_stride = p.Rp * (long)d->LP; a.nseg = 2 * p.n_mod; a.LP = d->LP;
     a.C = t.C; a.G = t.G; a.cond_dims = t.cond_dims; a.dlatents = t.dlatents; a.dcond = t.dcond;
@@ -863,6 +916,8 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
     a.coords = t.coords; a.dcoords = t.dcoords; a.dcn = (const float *)(w + p.dcn); a.embed = t.embed; a.dembed = t.dembed;
     a.offs = (const int32_t *)(w + p.offs); a.tf_dim = t.tf_dim; a.nparts = p.nparts; a.g_tf = (int)p.S;
   }
+  static const int tail_skip = getenv("CINEMA_NG_TAIL_SKIP") ? atoi(getenv("CINEMA_NG_TAIL_SKIP")) : 0;   // developer timing only
+  a.skip = tail_skip;
   const int grid = a.g_red + a.g_tab + a.g_tf + a.g_bias;
   if (grid == 0) return 0;
   hipLaunchKernelGGL(k_ng_tail, dim3((unsigned)grid), dim3(256), 0, s, a);
