@@ -22,7 +22,7 @@
 //   Vp     bf16 [S*32][16]          the same through final_linear.weight[:, H:]
 //   dU     bf16 [Rp][F], dUo16 bf16 [Rp][16], dUo32 fp32 [Rp][16]
 //   dcn    fp32 [nparts][Npad][4]   per-(tensor, column group) parts of d coords through the interpolation weights
-//   dT     fp32 [2 n_mod][Rp][LP]   per-segment parts of d (node rows)
+//   dT     fp32 [dt_parts][Rp][LP]  per-(segment, k piece) parts of d (node rows), dt_parts = 2 n_mod * dtk (+ 1: final_linear term)
 #pragma once
 #include "common.h"
 
@@ -32,6 +32,7 @@
 struct NgPlan {
   long S, Npad, Rp;
   int n_mod, F, nparts, ncg, HP, LP;
+  int dt_wide, dtk, dt_parts;        // node-row d-latent GEMM: kernel choice, k pieces per segment, parts it leaves in dT
   int layer_of[CINEMA_MAX_LAYERS];
   size_t offs, T, Tc, wt, wrow, axt, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
 };

@@ -792,7 +792,12 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   p.dUo16 = take((size_t)p.Rp * 16 * 2);
   p.dUo32 = take((size_t)p.Rp * 16 * 4);
   p.dcn = take((size_t)p.nparts * Npad * 4 * 4);
-  p.dT = take((size_t)2 * p.n_mod * p.Rp * d->LP * 4);
+  // node-row d-latent GEMM: k_dlat256 (siren.hip; k tiles of 64) when the shapes allow -- two k pieces per segment if they
+  // divide, and the final_linear term as a part of its own -- else k_dlat with one part per segment
+  p.dt_wide = (d->LP >= 192 && d->HP % 64 == 0) ? 1 : 0;
+  p.dtk = (p.dt_wide && d->HP % 128 == 0) ? 2 : 1;
+  p.dt_parts = 2 * p.n_mod * p.dtk + p.dt_wide;
+  p.dT = take((size_t)p.dt_parts * p.Rp * d->LP * 4);
   p.bytes = o;
   return p;
 }
@@ -907,7 +912,7 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   a.S = p.S; a.Npad = p.Npad; a.N = (long)t.N;
   if (t.grad_params != nullptr) { a.gp = t.grad_params; a.g_bias = (p.F + 31) / 32; }
   if (t.dlatents != nullptr) {
-    a.dT = (const float *)(w + p.dT); a.part_stride = p.Rp * (long)d->LP; a.nseg = 2 * p.n_mod; a.LP = d->LP;
+    a.dT = (const float *)(w + p.dT); a.part_stride = p.Rp * (long)d->LP; a.nseg = p.dt_parts; a.LP = d->LP;
     a.C = t.C; a.G = t.G; a.cond_dims = t.cond_dims; a.dlatents = t.dlatents; a.dcond = t.dcond;
     a.tab_cs = (d->LP + 63) / 64;
     a.g_tab = (int)(p.S * a.tab_cs);
