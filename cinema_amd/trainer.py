@@ -172,6 +172,7 @@ class HotPathTrainer:
         self.prep_scratch = torch.zeros(_lib.PREPARE_SCRATCH, device=self.device)
         self.ev_prep = torch.cuda.Event()
         self.ev_head = torch.cuda.Event()
+        self.split_backward = False      # tests: a single rank walks the call order of a rank of several (weights first, table side second)
         self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
         self.nodes = E.NodeTables()                                    # node-space tables of the nodes path
         self.ng = E.NodeGrad()                                         # work buffer of the node-space backward
@@ -262,7 +263,7 @@ class HotPathTrainer:
                       labels=st.labels, voxels_per_subject=st.V, prepared=True, norm=None if norm is None else norm.wait())
         # one rank: nobody needs the flat gradient before the optimiser, so the split reduction of the weight-gradient
         # tiles rides with the K1 backward's first launch (beside the coordinate gradient) instead of a launch of its own
-        pending = self.pending if (grouped and self.train_mlp and self.world == 1) else None
+        pending = self.pending if (grouped and self.train_mlp and self.world == 1 and not self.split_backward) else None
         work = None
         want_tf = self.tfs.requires_grad
         if ng_on_side:
@@ -273,17 +274,19 @@ class HotPathTrainer:
             ng_args = dict(ng=self.ng, coords=coords, idx=subj, tfs=tfs, latents_shape=tuple(table.shape), cond_dims=self.cond_dims,
                            dlatents=self.lat_grad if self.conv is None else self.table_grad, dtfs=self.tf_grad if want_tf else None,
                            dcond=self.cond_grad if self.cond_param is not None else None)
-            if self.train_mlp and self.world > 1:
+            if self.train_mlp and (self.world > 1 or self.split_backward):
                 eng.backward_nodegrad(n, ws.dout, weight_grads=True, dcoords_cleared=True, part=_lib.BWD_WEIGHTS_FIRST, **ng_args)
-                work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+                if self.world > 1:
+                    work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
                 eng.backward_nodegrad(n, ws.dout, weight_grads=True, part=_lib.BWD_DLAT_ONLY, **ng_args)
             else:
                 eng.backward_nodegrad(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, **ng_args)
-        elif self.train_mlp and self.world > 1:
+        elif self.train_mlp and (self.world > 1 or self.split_backward):
             # rank of several: weight gradients first, their all-reduce starts at once and runs beside the d-latent GEMM,
             # the K1 backward and the table-side AdamW
             eng.backward(n, ws.dout, weight_grads=True, dcoords_cleared=True, part=_lib.BWD_WEIGHTS_FIRST)
-            work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
+            if self.world > 1:
+                work = par.allreduce_mean_(eng.flat_grad, self.pg, async_op=True)
             eng.backward(n, ws.dout, weight_grads=True, part=_lib.BWD_DLAT_ONLY)
         else:
             eng.backward(n, ws.dout, weight_grads=self.train_mlp, dcoords_cleared=True, pending=pending)

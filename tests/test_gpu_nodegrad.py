@@ -11,7 +11,7 @@ from test_gpu_trainer import DEV, base_args
 pytestmark = pytest.mark.gpu
 
 
-def _one_step(monkeypatch, node_grad, args, store, n, split="train", cond_seed=None):
+def _one_step(monkeypatch, node_grad, args, store, n, split="train", split_backward=False):
     from cinema_amd.trainer import HotPathTrainer
     from cinema_amd import engine as E
     monkeypatch.setenv("CINEMA_NODE_GRAD", "1" if node_grad else "0")
@@ -24,6 +24,7 @@ def _one_step(monkeypatch, node_grad, args, store, n, split="train", cond_seed=N
             if "linear_lats.weight" in k:
                 v.mul_(3.0)
     assert E.nodegrad_eligible(tr.eng, tuple(tr.latents.shape)) == node_grad
+    tr.split_backward = split_backward
     tr.step(0, n)
     torch.cuda.synchronize()
     out = {"glat": tr.lat_grad.clone(), "gtf": tr.tf_grad.clone(), "gflat": tr.eng.flat_grad.clone()}
@@ -74,4 +75,23 @@ def test_node_gradients_validation_split_with_conditions(monkeypatch):
         errs.update(both_errs(k, got[k].cpu().numpy(), ref[k].cpu().numpy()))
     assert float(got["gflat"].abs().max()) == 0.0
     bad = failing(errs, 1e-2, 6e-3)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("node_grad", [True, False])
+def test_two_call_backward_of_a_rank_of_several_equals_the_single_call(node_grad, monkeypatch):
+    """world > 1 calls the backward twice (BWD_WEIGHTS_FIRST, all-reduce starts, BWD_DLAT_ONLY): same gradients as one call."""
+    from cinema_amd.trainer import SubjectStore
+    S, side, n = 9, 22, 2900
+    args = base_args([64, 3, 3, 3], 256, 3, [1, 3], [2, 10], 0, "bf16")
+    store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 2, 10, seed=11, device=DEV)
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n)
+    ref, ref_v = _one_step(monkeypatch, node_grad, args, store, n)
+    got, got_v = _one_step(monkeypatch, node_grad, args, store, n, split_backward=True)
+    errs = {}
+    for k in ("glat", "gtf"):
+        errs.update(both_errs(k, got[k].cpu().numpy(), ref[k].cpu().numpy()))
+    for k in ref_v:
+        errs.update(both_errs("g_" + k, got_v[k].cpu().numpy(), ref_v[k].cpu().numpy()))
+    bad = failing(errs, 1e-5, 1e-5)        # the same kernels on the same operands; float atomics in the bias sums
     assert not bad, bad
