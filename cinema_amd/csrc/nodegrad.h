@@ -31,8 +31,7 @@
 
 struct NgPlan {
   long S, Npad, Rp;
-  int n_mod, F, nparts, ncg, HP, LP;
-  int dt_wide, dtk, dt_parts;        // node-row d-latent GEMM: kernel choice, k pieces per segment, parts it leaves in dT
+  int n_mod, F, nparts, ncg, HP, LP, dt_parts;
   int layer_of[CINEMA_MAX_LAYERS];
   size_t offs, T, Tc, wt, wrow, axt, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
 };
@@ -45,7 +44,7 @@ int ng_launch_rows(const cinema_siren_desc *d, void *work, const float *latents,
 
 // X -> dU, dUo, dcn (one launch).  gbuf: the backward scratch tensors (ds / dt slots, dOut16 in the last slot).
 int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, const void *gbuf, const float *coords_t,
-                   const int32_t *idx, int64_t N, int lx, int ly, int lz, hipStream_t s);
+                   const int32_t *idx, int64_t N, int lx, int ly, int lz, const void *packed, const float *params, hipStream_t s);
 
 // Tail of the backward in one launch (block ranges; NULL / 0 switches a range off):
 //   reduce:  split reduction of k_dw256's partial tiles (opaque Dw256Args, may be NULL)

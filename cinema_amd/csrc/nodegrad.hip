@@ -262,6 +262,9 @@ struct NgGradArgs {
   const bf16_t *wt, *wrow, *Up, *Vp; const int32_t *axt; const float *coords_t; const int32_t *offs;
   long N, Npad, S; int HP, F, lx, ly, lz, in_dim;
   bf16_t *dU, *dUo16; float *dUo32, *dcn;
+  // d (node rows) parts: part (t, cg) = dU tile x linear_lats^T (packed [LP][HP] copies), last part = dUo x final_linear[:, H:]
+  const bf16_t *packed; long pk_wlsT[CINEMA_MAX_LAYERS], pk_wltT[CINEMA_MAX_LAYERS]; const float *wf_lat; int wf_ld, out_dim, lat, LP;
+  float *dT; long dT_stride;
   int dbg;      // developer ablations (cinema_debug_node_grad): 1 = no exchange / d coords, 2 = no dU products, 4 = no dwn products
 };
 
@@ -484,14 +487,40 @@ __device__ __forceinline__ void ng_body_tensor(const NgGradArgs &a, const long s
       if (g < 3) RR[((((k - 1) & 1) * 2 + h) * 2 + mt) * 64 + i * 4 + g] = dc[g];
     }
   }
-  // dU rows of this subject: lane (i = slot, g): features c0 + 32 wave + 16 ft + 4 g .. + 3
-  if (kv) {
+  // dU rows of this subject: lane (i = slot, g): features c0 + 32 wave + 16 ft + 4 g .. + 3 -- to global memory (operand of
+  // the weight-gradient problems) and, as a swizzled image over the U' rows, to LDS
+  __syncthreads();                                           // every wave is out of the loop: U' and the rings are free
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+  for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-      for (int nt2 = 0; nt2 < 2; ++nt2)
-        *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + 16 * nt2 + i) * a.F + (long)t * a.HP + c0 + 32 * wave + 16 * ft + 4 * g) =
-            cvt4(dUa[ft][nt2]);
+    for (int nt2 = 0; nt2 < 2; ++nt2) {
+      const bf16x4 v = kv ? cvt4(dUa[ft][nt2]) : cvt4(zero4);
+      const int row = 16 * nt2 + i, colbyte = (32 * wave + 16 * ft + 4 * g) * 2;
+      if (kv) *reinterpret_cast<bf16x4 *>(a.dU + (s * NG_SLOTS + row) * a.F + (long)t * a.HP + c0 + 32 * wave + 16 * ft + 4 * g) = v;
+      *(LDS_AS bf16x4 *)(UP + row * 512 + ((((colbyte >> 4) ^ ng_key(row)) << 4) | (colbyte & 15))) = v;
+    }
+  __syncthreads();
+  // this workgroup's part of d (node rows): dT[slot][c] = sum_{f in its columns} dU[slot][f] * Wl[f][c]; C[m = c][n = slot],
+  // A = 16 rows of the transposed packed copy (all k steps requested before the first product), B = the LDS image
+  const bf16_t *WT = a.packed + (half ? a.pk_wltT[layer] : a.pk_wlsT[layer]) + c0;
+  float *dTp = a.dT + (long)part * a.dT_stride + s * NG_SLOTS * a.LP;
+  for (int ct = wave; ct < (a.LP >> 4); ct += 8) {
+    bf16x8 af[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) af[kk] = *reinterpret_cast<const bf16x8 *>(WT + (long)(16 * ct + i) * a.HP + 32 * (kk < nkk ? kk : 0) + 8 * g);
+    f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      if (kk < nkk) {
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) {
+          const bf16x8 bfr = *(const LDS_AS bf16x8 *)(UP + (16 * nt2 + i) * 512 + (((4 * kk + g) ^ ng_key(16 * nt2 + i)) << 4));
+          acc[nt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[nt2], 0, 0, 0);
+        }
+      }
+    // lane (i = slot, g): latent columns 16 ct + 4 g .. + 3
+#pragma unroll
+    for (int nt2 = 0; nt2 < 2; ++nt2) *reinterpret_cast<f32x4 *>(dTp + (16 * nt2 + i) * a.LP + 16 * ct + 4 * g) = acc[nt2];
   }
 }
 
@@ -502,6 +531,7 @@ __device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const bf16_t *X = a.gbuf + a.slot_elems * a.dout_slot;      // [Npad][16] bf16
+  float *Uo = &P[0][0][0] + 8 * 64 * 8;                       // [32 slots][16] behind the partials
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 sel0;
@@ -561,6 +591,24 @@ __device__ __forceinline__ void ng_body_dout(const NgGradArgs &a, const long s, 
       const long row = s * NG_SLOTS + 16 * nt + i;
       *reinterpret_cast<f32x4 *>(a.dUo32 + row * 16 + 4 * g) = t4;
       *reinterpret_cast<bf16x4 *>(a.dUo16 + row * 16 + 4 * g) = cvt4(t4);
+      *reinterpret_cast<f32x4 *>(Uo + (16 * nt + i) * 16 + 4 * g) = t4;
+    }
+  }
+  __syncthreads();
+  // the last part of d (node rows): dT[slot][c] = sum_o dUo[slot][o] * final_linear.weight[o][H + c], fp32; thread = (column,
+  // half of the slots)
+  float *dTp = a.dT + (long)part * a.dT_stride + s * NG_SLOTS * a.LP;
+  for (int c = tid & 255; c < a.LP; c += 256) {
+    float wv[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) wv[o] = (o < a.out_dim && c < a.lat) ? a.wf_lat[(long)o * a.wf_ld + c] : 0.f;
+    const int sl0 = (tid >> 8) * 16;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      float v = 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) v += Uo[(sl0 + q) * 16 + o] * wv[o];
+      dTp[(sl0 + q) * a.LP + c] = v;
     }
   }
 }
@@ -580,6 +628,10 @@ __global__ __launch_bounds__(512, 4) void k_node_grad(NgGradArgs a) {
         const int slot = q / (cols >> 3), ch = q - slot * (cols >> 3);
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4 *>(a.dU + (s * NG_SLOTS + slot) * a.F + (long)t * a.HP + 256 * cg + ch * 8) = z;
+      }
+      for (int q = threadIdx.x; q < NG_SLOTS * a.LP / 4; q += 512) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(a.dT + (long)part * a.dT_stride + s * NG_SLOTS * a.LP + 4 * q) = z;
       }
       return;
     }
@@ -792,11 +844,7 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   p.dUo16 = take((size_t)p.Rp * 16 * 2);
   p.dUo32 = take((size_t)p.Rp * 16 * 4);
   p.dcn = take((size_t)p.nparts * Npad * 4 * 4);
-  // node-row d-latent GEMM: k_dlat256 (siren.hip; k tiles of 64) when the shapes allow -- two k pieces per segment if they
-  // divide, and the final_linear term as a part of its own -- else k_dlat with one part per segment
-  p.dt_wide = (d->LP >= 192 && d->HP % 64 == 0) ? 1 : 0;
-  p.dtk = (p.dt_wide && d->HP % 128 == 0) ? 2 : 1;
-  p.dt_parts = 2 * p.n_mod * p.dtk + p.dt_wide;
+  p.dt_parts = p.nparts;                     // k_node_grad leaves one part of d (node rows) per workgroup kind
   p.dT = take((size_t)p.dt_parts * p.Rp * d->LP * 4);
   p.bytes = o;
   return p;
@@ -871,15 +919,16 @@ extern "C" int cinema_nodegrad_prepare(const cinema_siren_desc *d, const void *p
 
 static int g_ng_dbg = 0;
 extern "C" int cinema_debug_node_grad(const cinema_siren_desc *d, void *work, const void *gbuf, const float *coords_t, int64_t N,
-                                      int64_t Npad, int64_t S, int32_t lx, int32_t ly, int32_t lz, int32_t dbg, void *stream) {
+                                      int64_t Npad, int64_t S, int32_t lx, int32_t ly, int32_t lz, int32_t dbg,
+                                      const void *packed, const float *params, void *stream) {
   g_ng_dbg = dbg;       // developer hook (tools/time_nodegrad.py): k_node_grad alone, with ablation bits
-  const int rc = ng_launch_grad(d, ng_plan(d, S, Npad), work, gbuf, coords_t, nullptr, N, lx, ly, lz, (hipStream_t)stream);
+  const int rc = ng_launch_grad(d, ng_plan(d, S, Npad), work, gbuf, coords_t, nullptr, N, lx, ly, lz, packed, params, (hipStream_t)stream);
   g_ng_dbg = 0;
   return rc;
 }
 
 int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, const void *gbuf, const float *coords_t,
-                   const int32_t *idx, int64_t N, int lx, int ly, int lz, hipStream_t s) {
+                   const int32_t *idx, int64_t N, int lx, int ly, int lz, const void *packed, const float *params, hipStream_t s) {
   char *w = (char *)work;
   (void)idx;
   NgGradArgs a = {};
@@ -892,6 +941,11 @@ int ng_launch_grad(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   a.coords_t = coords_t; a.offs = (const int32_t *)(w + p.offs); a.ncg = p.ncg;
   a.N = (long)N; a.Npad = p.Npad; a.S = p.S; a.HP = d->HP; a.F = p.F; a.lx = lx; a.ly = ly; a.lz = lz; a.in_dim = d->in_dim;
   a.dU = (bf16_t *)(w + p.dU); a.dUo16 = (bf16_t *)(w + p.dUo16); a.dUo32 = (float *)(w + p.dUo32); a.dcn = (float *)(w + p.dcn);
+  a.packed = (const bf16_t *)packed;
+  for (int i = 0; i < d->n_layers; ++i) { a.pk_wlsT[i] = d->pk_wlsT[i]; a.pk_wltT[i] = d->pk_wltT[i]; }
+  a.wf_lat = params + d->off_wf + d->hidden; a.wf_ld = d->hidden + d->lat; a.out_dim = d->out_dim; a.lat = d->lat; a.LP = d->LP;
+  a.dT = (float *)(w + p.dT); a.dT_stride = p.Rp * (long)d->LP;
+  CINEMA_REQUIRE(d->out_dim <= 16 && d->LP % 16 == 0, "node gradients: out_dim %d > 16 or padded latent width %d", d->out_dim, d->LP);
   CINEMA_REQUIRE(p.S * p.nparts < (1L << 30), "node gradients: too many subjects");
   CINEMA_SMEM_ATTR(k_node_grad, NG_SMEM);
   hipLaunchKernelGGL(k_node_grad, dim3((unsigned)(p.S * p.nparts)), dim3(512), NG_SMEM, s, a);

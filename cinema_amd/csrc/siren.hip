@@ -299,25 +299,12 @@ struct DlatArgs {
   const float *Xs; int ldxs; int ks; const float *Ws; int ws_sf, ws_sk;
   int lat; int LP; int ldg;
   float *out; int tiles_f;
-  int seg_split; long part_stride;   // seg_split: workgroup = (segment, tile), segment sg writes its own part out + sg * part_stride
-  int ksplit;                        // k_dlat256 with seg_split: k pieces per segment, part index = sg * ksplit + piece
 };
 
 template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int sg0 = 0, ns = a.nseg;
-  float *out = a.out;
-  TileCtx c;
-  if (a.seg_split) {     // few rows (node space): the segments run side by side instead of in one k loop
-    const int ntile = gridDim.x / a.nseg;
-    sg0 = blockIdx.x / ntile;
-    c = make_ctx_id(blockIdx.x - sg0 * ntile, a.tiles_f);
-    ns = 1;
-    out += (size_t)sg0 * a.part_stride;
-  } else {
-    c = make_ctx(a.tiles_f);
-  }
+  const TileCtx c = make_ctx(a.tiles_f);
   f32x4 acc[4][4];
   {
     float zero[16];
@@ -325,15 +312,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_dlat(DlatArgs a) {
     for (int j = 0; j < 16; ++j) zero[j] = 0.f;
     acc_fill(acc, zero);
   }
-  if (sg0 == 0) smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
-  nt_mainloop_segs<T>(acc, a.seg + sg0, ns, c.f0, a.LP, c.n0, a.ldg, smem);
+  smallk_accumulate(acc, c, a.Xs, a.ldxs, a.ks, a.Ws, a.ws_sf, a.ws_sk, a.lat);
+  nt_mainloop_segs<T>(acc, a.seg, a.nseg, c.f0, a.LP, c.n0, a.ldg, smem);
   if (c.fb < a.LP) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = acc[j >> 2][st][j & 3];
-      store16(out + (size_t)c.nrow[st] * a.LP + c.fb, v);
+      store16(a.out + (size_t)c.nrow[st] * a.LP + c.fb, v);
     }
   }
 }
@@ -587,18 +574,7 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 8;
   const int wf = (wave >> 1) & 3, wn = wave & 1;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  int sg0 = 0, ns = a.nseg, ks = a.ks, kpiece = 0;
-  float *out = a.out;
-  if (a.seg_split) {     // few rows (node space): workgroup = (segment, k piece, tile); segment sg leaves its own part at out + sg * part_stride
-    // the small-K term is a part of its own (the last): behind a k loop it made its workgroups the launch's critical path
-    const int ntile = gridDim.x / (a.nseg * a.ksplit + 1);
-    const int part = id / ntile;
-    id -= part * ntile;
-    sg0 = part / a.ksplit; kpiece = part - sg0 * a.ksplit;
-    out += (size_t)part * a.part_stride;
-    if (part < a.nseg * a.ksplit) { ns = 1; ks = 0; } else { ns = 0; sg0 = 0; kpiece = 0; }
-  }
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
   TileCtx c;
   c.f0 = (id % a.tiles_f) * 256;
   c.n0 = (id / a.tiles_f) * 128;
@@ -606,10 +582,8 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   c.fb = c.f0 + wf * 64 + 16 * c.g;
 #pragma unroll
   for (int st = 0; st < 4; ++st) c.nrow[st] = c.n0 + wn * 64 + 16 * st + c.i;
-  const int K = a.seg[0].K;                           // the host takes this path only when every segment has this K
-  const int kps = a.seg_split ? K / DL256_BK / a.ksplit : K / DL256_BK;
-  const int kt0 = kpiece * kps;                       // first k tile of this workgroup's piece
-  const int nt = ns * kps;
+  const int K = a.seg[0].K, kps = K / DL256_BK;       // the host takes this path only when every segment has this K
+  const int nt = a.nseg * kps;
   f32x4 acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
@@ -619,7 +593,7 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
     const int d = wave - 8;
     auto src_of = [&](int t) {
       const int sg = t / kps;
-      Dl256Src q = {(const bf16_t *)a.seg[sg0 + sg].A, (const bf16_t *)a.seg[sg0 + sg].B, K, c.f0, a.LP, a.ldg, (kt0 + t - sg * kps) * DL256_BK,
+      Dl256Src q = {(const bf16_t *)a.seg[sg].A, (const bf16_t *)a.seg[sg].B, K, c.f0, a.LP, a.ldg, (t - sg * kps) * DL256_BK,
                     (long)c.n0};
       return q;
     };
@@ -657,38 +631,23 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
   }
   // The fp32 small-K term (dOut x final_linear.weight[:, H:], K = out_dim <= 16) goes last -- its ordinary loads must
   // not sit between the hand-counted DMAs above -- and through LDS: read per lane straight from global memory it is a
-  // chain of dependent, uncoalesced round trips.  All loads of a thread are requested before the first LDS store.
-  if (ks > 0) {                                         // workgroup-uniform
-    __syncthreads();
+  // chain of dependent, uncoalesced round trips.
+  __syncthreads();
+  {
     LDS_AS float *wl = (LDS_AS float *)base;            // [ks][256]: weight of latent feature f0 + l against output k
     LDS_AS float *xl = wl + 16 * 256;                   // [128][16]: dOut rows of the tile
-    float wv[6], xv0[3];                                // ks <= 16: at most 16 * 256 / 768 and 128 * 16 / 768 elements per thread
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int q = tid + DL256_THREADS * u;
+    for (int q = tid; q < a.ks * 256; q += DL256_THREADS) {
       const int k = q >> 8, f = c.f0 + (q & 255);
-      wv[u] = (q < ks * 256 && f < a.lat) ? a.Ws[(size_t)f * a.ws_sf + (size_t)k * a.ws_sk] : 0.f;
+      wl[q] = f < a.lat ? a.Ws[(size_t)f * a.ws_sf + (size_t)k * a.ws_sk] : 0.f;
     }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int q = tid + DL256_THREADS * u;
-      const int n = q / ks, k = q - n * ks;
-      xv0[u] = q < 128 * ks ? a.Xs[(size_t)(c.n0 + n) * a.ldxs + k] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int q = tid + DL256_THREADS * u;
-      if (q < ks * 256) wl[q] = wv[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int q = tid + DL256_THREADS * u;
-      const int n = q / ks, k = q - n * ks;
-      if (q < 128 * ks) xl[n * 16 + k] = xv0[u];
+    for (int q = tid; q < 128 * a.ks; q += DL256_THREADS) {
+      const int n = q / a.ks, k = q - n * a.ks;
+      xl[n * 16 + k] = a.Xs[(size_t)(c.n0 + n) * a.ldxs + k];
     }
     __syncthreads();
-    if (c.fb < a.LP && !loader)
-      for (int k = 0; k < ks; ++k) {
+    if (loader) return;
+    if (c.fb < a.LP)
+      for (int k = 0; k < a.ks; ++k) {
         float xv[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) xv[st] = xl[(wn * 64 + 16 * st + c.i) * 16 + k];
@@ -702,14 +661,13 @@ __global__ __launch_bounds__(DL256_THREADS) void k_dlat256(DlatArgs a) {
         }
       }
   }
-  if (loader) return;
   if (c.fb < a.LP) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = acc[j >> 2][st][j & 3];
-      store16(out + (size_t)c.nrow[st] * a.LP + c.fb, v);
+      store16(a.out + (size_t)c.nrow[st] * a.LP + c.fb, v);
     }
   }
 }
@@ -1131,7 +1089,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
         CINEMA_CHECK_HIP(hipGetLastError());
         dout_prep_done = wgrads;   // (its bias gradient was not taken: a weight-gradient pass would have to redo it)
       }
-      if (int rc = ng_launch_grad(d, ngp, ng->work, gbuf, coords_t, ng->idx, N, ng->lx, ng->ly, ng->lz, s)) return rc;
+      if (int rc = ng_launch_grad(d, ngp, ng->work, gbuf, coords_t, ng->idx, N, ng->lx, ng->ly, ng->lz, packed, params, s)) return rc;
     }
   }
   auto ng_tail = [&](const Dw256Args *red, bool weights_side, bool table_side) -> int {
@@ -1189,36 +1147,7 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
 
   // ---- d lat ----
   if (ng != nullptr && (phases & CINEMA_BWD_PHASE_DLAT)) {
-    // d (node rows) = sum_j (dU_s Wl_scale + dU_t Wl_shift) + dUo Wf[:, H:]  on S*32 node rows, one part per segment
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      DlatArgs a = {};
-      const bf16_t *dU = (const bf16_t *)((const char *)ng->work + ngp.dU);
-      int ns = 0;
-      for (int j = 0; j < ngp.n_mod; ++j) {
-        const int i = ngp.layer_of[j];
-        a.seg[ns].A = pk + d->pk_wlsT[i]; a.seg[ns].B = dU + (size_t)j * 2 * HP; a.seg[ns].K = HP; ++ns;
-        a.seg[ns].A = pk + d->pk_wltT[i]; a.seg[ns].B = dU + (size_t)j * 2 * HP + HP; a.seg[ns].K = HP; ++ns;
-      }
-      a.nseg = ns;
-      a.Xs = (const float *)((const char *)ng->work + ngp.dUo32); a.ldxs = 16; a.ks = d->out_dim;
-      a.Ws = params + d->off_wf + H; a.ws_sf = 1; a.ws_sk = H + L;
-      a.lat = L; a.LP = LP; a.ldg = ngp.F; a.out = (float *)((char *)ng->work + ngp.dT);
-      a.seg_split = 1; a.part_stride = ngp.Rp * (long)LP;
-      if (ngp.dt_wide) {                                   // one workgroup = all latent features of 128 node rows, one k piece
-        a.tiles_f = (LP + 255) / 256;
-        CINEMA_SMEM_ATTR(k_dlat256, DL256_SMEM);
-        static_assert(DL256_BK == 64, "ng_plan assumes k tiles of 64");
-        a.ksplit = ngp.dtk;
-        hipLaunchKernelGGL(k_dlat256, dim3(a.tiles_f * (int)(ngp.Rp / 128) * (ns * a.ksplit + 1)), dim3(DL256_THREADS), DL256_SMEM, s, a);
-      } else {
-        a.tiles_f = (LP + 127) / 128;
-        const int g2 = a.tiles_f * (int)(ngp.Rp / 128) * ns;
-        constexpr int smem = Engine<T>::NT_SMEM;
-        CINEMA_SMEM_ATTR(k_dlat<T>, smem);
-        hipLaunchKernelGGL((k_dlat<T>), dim3(g2), dim3(WG_THREADS), smem, s, a);
-      }
-      CINEMA_CHECK_HIP(hipGetLastError());
-    }
+    // d (node rows): k_node_grad left its parts (one per workgroup kind); the tail sums them into d table / d cond
     if (!wgrads || dlat_only) return ng_tail(nullptr, false, true);
   } else if (phases & CINEMA_BWD_PHASE_DLAT) {
     DlatArgs a = {};

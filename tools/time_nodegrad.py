@@ -30,12 +30,12 @@ E.nodegrad_prepare(eng, ng, coords, idx, latents, None, tfs, N)
 npad = E.round_up(N, 128)
 lib = eng.lib
 lib.cinema_debug_node_grad.argtypes = [C.POINTER(_lib.SirenDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 def run(dbg):
     _lib.check(lib.cinema_debug_node_grad(C.byref(d), _lib.ptr(ng.work), _lib.ptr(ws.gbuf), _lib.ptr(ws.coords_t), N, npad, S, 3, 3, 3,
-                                          dbg, eng.stream()), "debug_node_grad")
+                                          dbg, _lib.ptr(eng.packed), _lib.ptr(eng.flat), eng.stream()), "debug_node_grad")
 
 
 if os.environ.get("PREP"):
