@@ -355,6 +355,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(opt.warmup, total_steps):
         trainer.step(i * n, (i + 1) * n)
+    enqueued = time.perf_counter() - t0       # host side done: how far ahead of the GPU the launch loop runs
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -381,7 +382,7 @@ def main():
                                f"n_samples {n} per GPU per step, {opt.loss} + weighted CE, AdamW step included",
                    "global_batch": world * n, "parallelism": f"dp{world} (subjects sharded, MLP grads all-reduced)"},
         "step_mfma_tflops_per_gpu": step_tflops / world, "step_mfma_frac": step_tflops / world / peak,
-        "loss_last_step": losses,
+        "loss_last_step": losses, "host_enqueue_ms_per_step": enqueued / opt.steps * 1e3,
     }
     if rank == 0:
         if siren is not None:

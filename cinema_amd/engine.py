@@ -73,7 +73,7 @@ class Workspace:
         n = self.npad_cap
         self.coords_t = torch.empty(n, in_dim, device=device, dtype=torch.float32)
         self.lat = torch.empty(n, d.LP, device=device, dtype=dt)
-        self.saved = torch.empty(d.n_saved, n, d.HP, device=device, dtype=dt)
+        self._saved = None     # (n_saved, n, HP): allocated by the first access -- a forward that keeps nothing never pays for it
         self.out = torch.empty(n, d.out_dim, device=device, dtype=torch.float32)
         self.gbuf = None       # backward-only buffers are allocated on first use
         self.dlat = None
@@ -83,6 +83,14 @@ class Workspace:
         self._dt = dt
         self._device = device
         self._in_dim = in_dim
+
+    @property
+    def saved(self) -> torch.Tensor:
+        """Activations kept for the backward (18 x Npad x HP elements at cfg-D: 18.4 KB per row in bf16)."""
+        if self._saved is None:
+            d = self._d
+            self._saved = torch.empty(d.n_saved, self.npad_cap, d.HP, device=self._device, dtype=self._dt)
+        return self._saved
 
     def ensure_backward(self):
         if self.gbuf is None:

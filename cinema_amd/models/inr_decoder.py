@@ -133,10 +133,15 @@ class INR_Decoder(nn.Module):
         lib = _lib.load()
         st = self.sr_net.hot_state(dev)
         eng = st.engine
-        # step_size bounds the reference's per-forward memory; nothing here is kept per coordinate beyond a few hundred
-        # bytes, and the result does not depend on the chunking, so small values are raised to where the launches of a
-        # chunk stop being the cost (measured: 221 -> 250 M coords/s at 310^3 from 100 000 to 400 000)
-        chunk = int(min(max(step_size, self.min_inference_chunk), n))
+        # step_size bounds the reference's per-forward memory.  On the activation-stationary bf16 kernels a forward keeps
+        # nothing per coordinate beyond its workspace rows (coords 12 B + bf16 latent row 2 LP B + 4 out_dim B, 0.57 KB at
+        # cfg-D; the saved-activation tensor is never allocated), and the result does not depend on the chunking, so small
+        # values are raised to where the launches of a chunk stop being the cost (0.3 GB at 2^19 rows; measured 221 -> 250
+        # M coords/s at 310^3 from 100 000 to 400 000).  Every other path (fp32, hidden > 512, CINEMA_SIREN_LAYERED=1)
+        # writes its activations (n_saved x HP elements per row: 18.4 KB bf16 / 36.9 KB fp32 at cfg-D) and honours step_size.
+        floor = self.min_inference_chunk if eng.can_skip_saved() else 1
+        chunk = int(min(max(step_size, floor), n))
+        ws_before = eng.ws
         with torch.no_grad():
             table = self.modulator(latent_vec).detach().to(device=dev, dtype=torch.float32).contiguous()
             if table.dim() != 5 or table.shape[0] != 1:
@@ -182,6 +187,8 @@ class INR_Decoder(nn.Module):
                                                   stream), "cinema_infer_chunk")
             _lib.check(lib.cinema_infer_rescale(_lib.ptr(vol), n, self.out_dim, sr, _lib.ptr(minmax), stream),
                        "cinema_infer_rescale")
+        if ws_before is not None and eng.ws is not ws_before:
+            eng.ws = ws_before      # a training workspace shared with this engine keeps its size (the chunk's one is dropped)
         modalities_rec = vol.reshape(list(img_shape) + [-1])
         if self.args.get("mask_reconstruction", False):
             from ..postmask import mask_reconstruction       # models/inr_decoder.py:59-60, 87-107, on the GPU

@@ -131,9 +131,9 @@ def _host_stage(t: torch.Tensor) -> torch.Tensor:
     key = (t.numel(), t.dtype)
     buf = _HOST_STAGE.get(key)
     if buf is None:
-        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True).view(t.shape)
+        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
         _HOST_STAGE[key] = buf
-    return buf
+    return buf.view(t.shape)      # the cache holds the flat buffer: tensors of equal size and different shape share it
 
 
 def broadcast_(tensor: torch.Tensor, src: int = 0, process_group=None):

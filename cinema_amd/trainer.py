@@ -155,12 +155,8 @@ class HotPathTrainer:
         else:
             self.opt_local = HipAdamW(groups, clear_grads=not self.keep_grads)
             self.opt_mlp = HipAdamW([mlp_group], clear_grads=not self.keep_grads) if self.train_mlp else None
-        self.schedulers = []
-        if o.get("scheduler", {}).get("type") == "cosine":
-            T = args["epochs"][split]
-            for opt in (self.opt_local, self.opt_mlp):
-                if opt is not None:
-                    self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
+        self._base_lrs = [[g["lr"] for g in opt.param_groups] for opt in (self.opt_local, self.opt_mlp) if opt is not None]
+        self._build_schedulers()
         self.sums = torch.zeros(4, device=self.device)
         self.norm = torch.zeros(2, device=self.device)               # union-batch normaliser of a data-parallel rank
         self.cond_grad = None
@@ -420,6 +416,21 @@ class HotPathTrainer:
             eng.grads_clean = True
         self.n_last = n
 
+    def _build_schedulers(self):
+        """build_atlas.py:455-457: fresh CosineAnnealingLR objects on the configured learning rates (also after a checkpoint
+        load: the reference builds optimiser and scheduler anew there)."""
+        o = self.args["optimizer"]
+        self.schedulers = []
+        opts = [opt for opt in (self.opt_local, self.opt_mlp) if opt is not None]
+        for opt, lrs in zip(opts, self._base_lrs):
+            for g, lr in zip(opt.param_groups, lrs):
+                g["lr"] = lr
+                g.pop("initial_lr", None)
+        if o.get("scheduler", {}).get("type") == "cosine":
+            T = self.args["epochs"][self.split]
+            for opt in opts:
+                self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=o["scheduler"]["eta_min"]))
+
     def _add_tf_regulariser_grad(self, subj, n):
         """d/d table of tf_weight * (mean(tfs[idx,0:3]^2) + mean(tfs[idx,3:6]^2) [+ scale term])  (utils.py:98-103)."""
         counts = torch.bincount(subj.long(), minlength=self.tfs.shape[0]).to(torch.float32).unsqueeze(1)
@@ -493,6 +504,7 @@ class HotPathTrainer:
         for opt in (self.opt_local, self.opt_mlp):
             if opt is not None:
                 opt.state.clear()
+        self._build_schedulers()        # a load starts optimiser AND schedule afresh (build_atlas.py:385, 455-457)
         return chkp
 
     def re_init_latents(self):
@@ -500,8 +512,16 @@ class HotPathTrainer:
         with torch.no_grad():
             self.latents.data.normal_(0, 0.01)
             self.tfs.data.zero_()
-        for g in (self.lat_grad, self.tf_grad, self.eng.flat_grad):
-            g.zero_()
+        # optimizer.zero_grad() of the reference covers every parameter group
+        grads = [self.lat_grad, self.tf_grad, self.eng.flat_grad, self.cond_grad] + [prm.grad for prm in self.conv_params]
+        if self.conv is not None:
+            grads.append(self.table_grad)
+        if self.cond_param is not None:
+            grads.append(self.cond_param.grad)
+        for g in grads:
+            if g is not None:
+                g.zero_()
+        self.eng.grads_clean = True
 
     def loss_dict(self) -> Dict[str, float]:
         """Losses of the LAST step with the reference's keys (one device->host sync; call every k steps)."""

@@ -262,7 +262,10 @@ int cinema_affine_trilerp_bwd_sorted(const float *coords, const int32_t *idx, co
  * The grouping scratch lives in a file-scope device array of the library (2*MAX_S + 2 + 13*MAX_N 4-byte words = 3.3 MiB
  * per GPU the library runs on, held until the process ends); sizes beyond the maxima are rejected with an error.  The
  * call allocates and frees nothing.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two
- * streams, two host threads) race -- serialise them.  Same outputs as cinema_affine_trilerp_bwd. */
+ * streams, two host threads) race -- serialise them.  Same outputs as cinema_affine_trilerp_bwd.
+ * Before a HIP graph capture: make ONE ordinary (eager) call on each device first.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress, which may load the code object) and keeps it; that lookup must not happen
+ * inside a capture.  Later calls on the device make no runtime call besides the kernel launches. */
 #define CINEMA_NOALLOC_MAX_N 65536
 #define CINEMA_NOALLOC_MAX_S 4096
 int cinema_affine_trilerp_bwd_noalloc(const float *coords, const int32_t *idx, const float *embed, int32_t tf_dim,

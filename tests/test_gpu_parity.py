@@ -535,3 +535,33 @@ def test_decoder_with_conv_modulator_matches_oracle():
     errs.update(both_errs("g_final_w", dec.sr_net.final_linear.weight.grad.cpu().numpy(), params["final_linear.weight"].grad.numpy()))
     bad = failing(errs, TOL["fp32"], L2_TOL["fp32"])
     assert not bad, f"{bad}\nall: {errs}"
+
+
+def test_inference_memory_follows_the_path(monkeypatch):
+    """The default 2^19-row chunk floor applies only where a forward keeps nothing (bf16 chain kernels): there the
+    saved-activation tensor is never allocated; the fp32 stack writes its activations and keeps step_size as its memory
+    bound.  A workspace grown by an inference call does not stay with an engine that already had one."""
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    n_vox = 9 * 9 * 9
+    coords = torch.rand(n_vox, 3, device=dev()) * 2 - 1
+    for prec, hidden in (("bf16", 128), ("fp32", 64)):
+        args = make_args([16, 3, 3, 3], hidden, 2, [1, 2], [2, 5], 0, prec)
+        torch.manual_seed(3)
+        dec = INR_Decoder(args, "cuda:0").to(dev())
+        lat = torch.randn(1, 16, 3, 3, 3, device=dev()) * 0.1
+        eng = dec.sr_net.hot_state(dev()).engine
+        assert eng.ws is None
+        vol = dec.inference(coords, lat, torch.zeros(0, device=dev()), [9, 9, 9], None, step_size=200)
+        assert vol.shape == (9, 9, 9, 2 + 1 + 5)
+        if prec == "bf16":
+            assert eng.can_skip_saved() and eng.ws._saved is None            # nothing kept, nothing allocated
+            assert eng.ws.npad_cap >= n_vox                                   # whole volume in one chunk (floor 2^19, capped at n)
+        else:
+            assert not eng.can_skip_saved() and eng.ws._saved is not None
+            assert eng.ws.npad_cap == 256                                     # step_size = 200 rows, padded to the row alignment
+        # an engine that already has a (training-sized) workspace gets it back after a larger inference chunk
+        if prec == "bf16":
+            eng.ws = None
+            small = eng.workspace(128)
+            dec.inference(coords, lat, torch.zeros(0, device=dev()), [9, 9, 9], None, step_size=200)
+            assert eng.ws is small

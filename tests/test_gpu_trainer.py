@@ -524,3 +524,30 @@ def test_checkpoint_round_trip(tmp_path):
     assert tr.save_state(9) is None and not os.path.exists(os.path.join(str(tmp_path), "checkpoint_epoch_9.pth"))
     tr.re_init_latents()
     assert float(tr.tfs.detach().abs().max()) == 0.0 and 0.005 < float(tr.latents.detach().std()) < 0.02
+
+
+def test_reinit_and_checkpoint_load_start_afresh(tmp_path):
+    """re_init_latents zeroes the gradient of every parameter group (optimizer.zero_grad(), build_atlas.py:427-430) and
+    load_checkpoint restarts optimiser state AND the cosine schedule (the reference builds both anew after a load)."""
+    from cinema_amd.trainer import HotPathTrainer, SubjectStore
+    args = base_args([16, 3, 3, 3], 64, 2, [1, 2], [1, 4], 1, "bf16")
+    args["optimizer"]["scheduler"] = {"type": "cosine", "eta_min": 1e-6}
+    args["epochs"] = {"train": 5, "val": 5}
+    args["output_dir"] = str(tmp_path)
+    store = SubjectStore.synthetic(3, (12, 12, 12), 155.0 / 12, [155, 155, 155], 1, 4, seed=2, device=DEV, cond_dims=1)
+    tr = HotPathTrainer(args, store, DEV, keep_grads=True, split="val")
+    lr0 = [g["lr"] for g in tr.opt_local.param_groups]
+    tr.epoch(400, torch.Generator(device=DEV).manual_seed(1), max_steps=2)
+    tr.epoch(400, torch.Generator(device=DEV).manual_seed(2), max_steps=2)
+    assert [g["lr"] for g in tr.opt_local.param_groups] != lr0
+    assert float(tr.cond_param.grad.abs().max()) > 0 and float(tr.lat_grad.abs().max()) > 0
+    tr.re_init_latents()
+    assert float(tr.cond_param.grad.abs().max()) == 0 and float(tr.lat_grad.abs().max()) == 0 and float(tr.tf_grad.abs().max()) == 0
+    assert tr.eng.grads_clean and float(tr.eng.flat_grad.abs().max()) == 0
+    path = tr.save_state(1)
+    assert path is not None
+    tr.load_checkpoint(str(tmp_path), 1)
+    assert [g["lr"] for g in tr.opt_local.param_groups] == lr0
+    assert all(s.last_epoch == 0 for s in tr.schedulers) and len(tr.opt_local.state) == 0
+    tr.epoch(400, torch.Generator(device=DEV).manual_seed(3), max_steps=1)      # and it still trains
+    assert [g["lr"] for g in tr.opt_local.param_groups] != lr0
