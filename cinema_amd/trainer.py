@@ -172,7 +172,7 @@ class HotPathTrainer:
         self.pending = C.create_string_buffer(_lib.PENDING_BYTES)    # host-side hand-over of the deferred reduction
         self.nodes = E.NodeTables()                                    # node-space tables of the nodes path
         self.ng = E.NodeGrad()                                         # work buffer of the node-space backward
-        self.n_last = 0
+        self.n_last, self.lo_last = 0, 0
         self.tf_weight = o["tf_weight"]
         self.loss_metric = "mse" if o["loss_metric"] == "mse" else "l1"
 
@@ -313,7 +313,7 @@ class HotPathTrainer:
             self.opt_mlp.step()
         if self.train_mlp and not self.keep_grads:
             eng.grads_clean = True                   # the clearing AdamW consumed and zeroed flat_grad
-        self.n_last = n
+        self.n_last, self.lo_last = n, lo
 
     def _latent_table(self):
         """What K1 interpolates: the latents, or their Conv3d modulation (one C-ABI call per step)."""
@@ -414,7 +414,7 @@ class HotPathTrainer:
             self.opt_mlp.step()
         if self.train_mlp and not self.keep_grads:
             eng.grads_clean = True
-        self.n_last = n
+        self.n_last, self.lo_last = n, lo
 
     def _build_schedulers(self):
         """build_atlas.py:455-457: fresh CosineAnnealingLR objects on the configured learning rates (also after a checkpoint
@@ -524,12 +524,28 @@ class HotPathTrainer:
         self.eng.grads_clean = True
 
     def loss_dict(self) -> Dict[str, float]:
-        """Losses of the LAST step with the reference's keys (one device->host sync; call every k steps)."""
+        """Losses of the LAST step with the reference's eight keys (Criterion.forward, utils.py:88-104): `seg` carries
+        seg_weight and `total` applies it again, the tf terms are means over the batch's gathered rows tfs[idcs_df]
+        (here: the table's rows weighted by the subjects' sample counts), `total` includes tf_weight * tf.
+        sr / seg are the sums the last step's loss kernel left (parameters BEFORE that step's update, as the reference
+        logs them); the tf terms are evaluated on the table as it is now, i.e. after that update -- one AdamW step away
+        from the reference's logged value (the gradient of the term, _add_tf_regulariser_grad, uses the pre-update
+        table).  One device->host sync; call every k steps."""
         s = self.sums.tolist()
         n = max(self.n_last, 1)
         sr = s[0] / (n * self.sr_dims)
         den = s[2] if self.class_w is not None else float(n)
         ce = s[1] / den if (self.seg_weight > 0 and den > 0) else 0.0
-        out = {"sr": sr, "seg": self.seg_weight * ce, "trafo": 0.0}
-        out["total"] = out["sr"] + self.seg_weight * out["seg"]
+        out = {"seg": self.seg_weight * ce, "sr": sr, "trafo": 0.0, "total": 0.0}
+        tf = 0.0
+        if self.tfs.requires_grad and self.n_last > 0:        # tf_dim > 0: the reference hands tfs[idcs_df] to the criterion
+            lo = self.lo_last
+            subj = self.store.subj[lo:lo + self.n_last]
+            counts = torch.bincount(subj.long(), minlength=self.tfs.shape[0]).to(torch.float64)
+            sq = (self.tfs.data.double() ** 2 * counts.unsqueeze(1)).sum(0) / (3.0 * self.n_last)
+            sq = sq.tolist()
+            out["tf_rot"], out["tf_trans"] = sum(sq[0:3]), sum(sq[3:6])
+            out["tf_scale"] = sum(sq[6:9]) if self.tfs.shape[1] == 9 else 0.0
+            out["tf"] = tf = out["tf_rot"] + out["tf_trans"] + out["tf_scale"]
+        out["total"] = out["sr"] + self.seg_weight * out["seg"] + self.tf_weight * tf
         return out

@@ -11,12 +11,12 @@ T = torch.from_numpy
 DEV = "cuda:0"
 
 
-def base_args(latent_dim, hidden, layers, mod, out_dim, cond, precision, loss_metric="mse", tf_weight=0.0, cw="default"):
+def base_args(latent_dim, hidden, layers, mod, out_dim, cond, precision, loss_metric="mse", tf_weight=0.0, cw="default", tf_dim=6):
     ncls = out_dim[-1]
     return {
         "inr_decoder": {"in_dim": 3, "out_dim": out_dim, "latent_dim": latent_dim, "cond_dims": cond, "hidden_size": hidden,
                         "num_hidden_layers": layers, "modulated_layers": mod, "omega": [30, 30], "cnn_kernel_size": 0,
-                        "tf_dim": 6, "precision": precision},
+                        "tf_dim": tf_dim, "precision": precision},
         "optimizer": {"tf_weight": tf_weight, "loss_metric": loss_metric, "seg_weight": 1.0, "lr_inr": 1e-4,
                       "inr_weight_decay": 0.0, "lr_latent": 5e-4, "latent_weight_decay": 0.0, "lr_tf": 7.5e-3,
                       "tf_weight_decay": 0.0, "scheduler": {"type": "cosine", "eta_min": 2.5e-5}},
@@ -114,11 +114,21 @@ def test_trainer_step_nodes_path_matches_oracle(shape, monkeypatch):
         _trainer_step_vs_oracle("bf16", True, S=64, side=28, latent_dim=[256, 3, 3, 3], hidden=512, layers=5, mod=[1, 3, 5], n=25000, nodes=True)
 
 
-def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, layers, mod, n, nodes=False):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_trainer_step_l1_scaling_tfs_and_tf_regulariser_match_oracle(precision):
+    """The reference's default loss_metric 'l1' (config_atlas.yaml:64), 9-wide tf rows (rigid + scaling, :73) and a
+    non-zero tf_weight (utils.py:97-103): loss dictionary with the reference's eight keys, gradients incl. the
+    regulariser's part of d tfs, one AdamW step."""
+    _trainer_step_vs_oracle(precision, True, S=5, side=24, latent_dim=[48, 3, 3, 3], hidden=128, layers=3, mod=[1, 3], n=700,
+                            loss_metric="l1", tf_weight=0.1, tf_dim=9)
+
+
+def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, layers, mod, n, nodes=False, loss_metric="mse",
+                            tf_weight=0.0, tf_dim=6):
     from oracle import cinema_oracle as O
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
     tol = 1e-4 if precision == "fp32" else 2e-2
-    args = base_args(latent_dim, hidden, layers, mod, [2, 10], 0, precision, tf_weight=0.0)
+    args = base_args(latent_dim, hidden, layers, mod, [2, 10], 0, precision, tf_weight=tf_weight, loss_metric=loss_metric, tf_dim=tf_dim)
     torch.manual_seed(21)
     store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 2, 10, seed=7, device=DEV)
     assert len(store) >= 2 * n
@@ -128,14 +138,15 @@ def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, lay
     tr = HotPathTrainer(args, store, DEV, keep_grads=True)
     with torch.no_grad():
         tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+    assert tr.tfs.shape[1] == tf_dim
     lat0, tf0, flat0 = tr.latents.detach().cpu().clone(), tr.tfs.detach().cpu().clone(), tr.eng.flat.detach().cpu().clone()
     coords, voxel, subj = store.coords[:n].cpu(), store.voxel[:n].cpu(), store.subj[:n].cpu()
     base = subj.long() * store.V + voxel
     target = torch.cat((store.intens.cpu()[base], store.labels.cpu()[base].float().unsqueeze(1)), 1)
     params = {k: v.clone().requires_grad_(True) for k, v in tr.eng.param_views(flat0).items()}
     lat_o, tf_o = lat0.clone().requires_grad_(True), tf0.clone().requires_grad_(True)
-    cfg = dict(num_hidden_layers=layers, omega=[30, 30], sr_dims=2, loss_metric="mse",
-               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=0.0)
+    cfg = dict(num_hidden_layers=layers, omega=[30, 30], sr_dims=2, loss_metric=loss_metric,
+               class_weights=torch.tensor(args["dataset"]["class_weights"]), tf_weight=tf_weight)
     loss_o, _ = O.training_step(params, lat_o, tf_o, coords, target, subj, None, cfg)
     # K3 sampled exactly these targets (bit-exact labels and intensities)
     tgt_dev = torch.empty(n, 3, device=DEV)
@@ -144,11 +155,22 @@ def _trainer_step_vs_oracle(precision, grouped, S, side, latent_dim, hidden, lay
     tr.step(0, n)
     sums = torch.zeros(4, device=DEV)
     dout = torch.empty(E.round_up(n, 128), 12, device=DEV)
-    E.sample_loss(None, tr.eng.ws.out, n, 2, 10, "mse", tr.class_w, 1.0, 1.0, dout, sums, voxel=store.voxel[:n],
+    E.sample_loss(None, tr.eng.ws.out, n, 2, 10, loss_metric, tr.class_w, 1.0, 1.0, dout, sums, voxel=store.voxel[:n],
                   subj=store.subj[:n], intens=store.intens, labels=store.labels, voxels_per_subject=store.V, target_out=tgt_dev)
     assert torch.equal(tgt_dev.cpu(), target)
     got = tr.loss_dict()
-    assert abs(got["total"] - float(loss_o["total"])) < tol * abs(float(loss_o["total"]))
+    # the reference's eight keys (utils.py:88-104); sr / seg belong to the parameters before the step, the tf terms are
+    # evaluated on the table after it (loss_dict's docstring) -- compared with the criterion on exactly those rows
+    assert set(got) == {"seg", "sr", "trafo", "total", "tf_rot", "tf_trans", "tf_scale", "tf"}
+    for k in ("sr", "seg"):
+        assert abs(got[k] - float(loss_o[k])) < tol * abs(float(loss_o[k])), (k, got[k], float(loss_o[k]))
+    tf_now = O.criterion(torch.zeros(n, 12), target, tr.tfs.detach().cpu()[subj.long()], 2, loss_metric, None, tf_weight)
+    for k in ("tf_rot", "tf_trans", "tf_scale", "tf"):
+        assert abs(got[k] - float(tf_now[k])) <= 1e-5 * abs(float(tf_now[k])) + 1e-12, (k, got[k], float(tf_now[k]))
+    if tf_dim == 9:
+        assert got["tf_scale"] > 0
+    want_total = float(loss_o["sr"]) + 1.0 * float(loss_o["seg"]) + tf_weight * float(tf_now["tf"])
+    assert abs(got["total"] - want_total) < tol * abs(want_total)
     errs = both_errs("glat", tr.lat_grad.cpu().numpy(), lat_o.grad.numpy())
     errs.update(both_errs("gtf", tr.tf_grad.cpu().numpy(), tf_o.grad.numpy()))
     gviews = tr.eng.param_views(tr.eng.flat_grad.cpu())
