@@ -85,6 +85,7 @@ class INR_Decoder(nn.Module):
                             modulated_layers=a["modulated_layers"], precision=precision)
         self._nodes = None           # node tables of the dense-inference path (engine.NodeTables), made on first use
         self.min_inference_chunk = 1 << 19
+        self.last_minmax = None
 
     # ------------------------------------------------------------------------------------
     def forward(self, coords, latent_vecs, condition_vecs, tfs=None, idcs_df=None, tf_table: bool = False):
@@ -189,6 +190,7 @@ class INR_Decoder(nn.Module):
                        "cinema_infer_rescale")
         if ws_before is not None and eng.ws is not ws_before:
             eng.ws = ws_before      # a training workspace shared with this engine keeps its size (the chunk's one is dropped)
+        self.last_minmax = minmax       # [min per modality | max per modality] of the clamped intensities (device tensor)
         modalities_rec = vol.reshape(list(img_shape) + [-1])
         if self.args.get("mask_reconstruction", False):
             from ..postmask import mask_reconstruction       # models/inr_decoder.py:59-60, 87-107, on the GPU

@@ -418,7 +418,68 @@ def test_inference_nodes_path_matches_per_sample_path(cond_dims, monkeypatch):
     assert torch.equal(torch.isnan(vol_n), torch.isnan(vol_p))
     inten = (torch.nan_to_num(vol_n[..., :2]) - torch.nan_to_num(vol_p[..., :2])).abs().max()
     assert float(soft) < 2e-2 and float(inten) < 2e-2, (float(soft), float(inten))
-    assert float((vol_n[..., 2] != vol_p[..., 2]).float().mean()) < 2e-2      # argmax flips only where two classes tie
+    flips = float((vol_n[..., 2] != vol_p[..., 2]).float().mean())            # argmax flips only where two classes tie
+    print(f"[nodes-vs-per-sample cond={cond_dims}] soft {float(soft):.2e} inten {float(inten):.2e} argmax flips {flips:.2e}", flush=True)
+    assert flips < FLIP_BOUND
+
+
+FLIP_BOUND = 2e-3       # measured: no flip at all on these grids (9 - 10 k voxels); one or two ties may flip on another seed
+
+
+def test_inference_full_310_volume_sampled_against_oracle():
+    """BASELINE config 4 at FULL size: one 310^3 volume (29.8 M coordinates) through INR_Decoder.inference on the cfg-D
+    stack (bf16, nodes path, WorldGrid coordinates made on the GPU), and 8 192 randomly chosen grid points of it against
+    the CPU oracle on those coordinates: soft labels, the clamped intensities before the whole-volume min-max (undone
+    with the min / max the call leaves in `last_minmax`), hard labels wherever the oracle's top two logits are apart."""
+    from oracle import cinema_oracle as O
+    from cinema_amd import engine as E
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    from cinema_amd.utils import generate_world_grid
+    args = make_args([256, 3, 3, 3], 512, 5, [1, 3, 5], [2, 10], 0, "bf16")
+    args["atlas_gen"] = {"spacing": [0.5, 0.5, 0.5]}
+    args["dataset"]["world_bbox"] = [155, 155, 155]
+    torch.manual_seed(11)
+    dec = INR_Decoder(args, "cuda:0").to(dev())
+    # a fresh SIREN answers with near-zero outputs: give the heads a range in which clamp, min-max and softmax matter
+    sd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    sd["sr_net.final_linear.weight"] *= 12.0
+    sd["sr_net.final_linear.weight"][2:] *= 8.0          # class logits a few units apart
+    sd["sr_net.final_linear.bias"][:2] = 0.5
+    dec.load_state_dict(sd)
+    lat = torch.randn(1, 256, 3, 3, 3, device=dev()) * 0.1
+    tf = (torch.rand(6, device=dev()) - 0.5) * 0.1
+    grid, shape, _ = generate_world_grid(args, device=dev(), lazy=True)
+    assert shape == [310, 310, 310]
+    assert E.nodes_inference_eligible(dec.sr_net.hot_state(dev()).engine, (1, 256, 3, 3, 3))
+    vol = dec.inference(grid, lat, torch.zeros(0, device=dev()), shape, tf)        # default step_size, default chunk floor
+    assert vol.shape == (310, 310, 310, 2 + 1 + 10)
+    G = 310 ** 3
+    pick = torch.randint(0, G, (8192,), generator=torch.Generator().manual_seed(3))
+    ix, iy, iz = pick // (310 * 310), (pick // 310) % 310, pick % 310
+    ax = [a.cpu() for a in grid.axes]
+    coords = torch.stack((ax[0][ix], ax[1][iy], ax[2][iz]), 1)
+    got = vol.reshape(G, -1)[pick.to(dev())].cpu()
+    mm = dec.last_minmax.cpu()
+    params = {k[len("sr_net."):]: v.detach().cpu() for k, v in dec.state_dict().items() if k.startswith("sr_net.")}
+    out = O.decoder_forward(params, coords, lat.cpu(), None, tf.cpu().reshape(1, 6).expand(8192, 6), torch.zeros(8192, dtype=torch.int64),
+                            5, 30, 30)
+    inten_o = out[:, :2].clamp(0, 1)
+    inten_g = got[:, :2] * (mm[2:] - mm[:2]) + mm[:2]
+    soft_o = torch.softmax(out[:, 2:], -1)
+    e_int, e_soft = float((inten_g - inten_o).abs().max()), float((got[:, 3:] - soft_o).abs().max())
+    top2 = out[:, 2:].topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    hard_o = out[:, 2:].argmax(-1).float()
+    flip = got[:, 2] != hard_o
+    print(f"[310^3 vs oracle] oracle intensities in [{float(out[:, :2].min()):.2f}, {float(out[:, :2].max()):.2f}], largest soft label "
+          f"{float(soft_o.max()):.2f}, min/max of the volume {mm.tolist()}", flush=True)
+    print(f"[310^3 vs oracle] intensities {e_int:.2e} soft labels {e_soft:.2e} argmax flips {float(flip.float().mean()):.2e}, "
+          f"largest oracle margin at a flip {float(margin[flip].max()) if bool(flip.any()) else 0.0:.2e}", flush=True)
+    # measured on MI355X: intensities 6.8e-4, soft labels 7.5e-4, 0.16 % argmax flips, all where the oracle's two top
+    # logits are < 4e-3 apart (logits of a few units) -- bounds = that with a margin of 4-5 x
+    assert e_int < 3e-3 and e_soft < 3e-3, (e_int, e_soft)
+    assert not bool((flip & (margin > 2e-2)).any())
+    assert float(flip.float().mean()) < 8e-3
 
 
 def test_state_dict_roundtrip_and_deepcopy():
