@@ -87,26 +87,47 @@ def cpu_baseline(args, trainer, n_samples, lat0, tf0, flat0, budget_s=25.0):
             "one_thread": {"value": m1 / med1, "cores": 1, "sample": f"{k1} timed step(s) on the first {m1} samples of that batch"}}
 
 
-PMC_FILES = {"FETCH_SIZE": "r02_pmc_fetch.txt", "WRITE_SIZE": "r02_pmc_write.txt"}
+PROFILE_TAG = "r03"                 # profiles/<tag>_*: rocprofv3 passes of `bench.py --profile-step` on this tree (tools/profile_round.sh)
+PMC_FILES = {"FETCH_SIZE": PROFILE_TAG + "_pmc_fetch.txt", "WRITE_SIZE": PROFILE_TAG + "_pmc_write.txt"}
 
 
-def pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload (profiles/r02_pmc_*:
-    separate --pmc runs of `bench.py --profile-step`, tools/profile_round.sh).  Counters are in KiB; FETCH_SIZE is doubled
-    as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (128-B requests tallied at
-    64 B), WRITE_SIZE is exact.  A live run cannot collect counters on itself, so this is the profile of the same
-    command, not of this process; None when the files are absent."""
-    vals = {}
+def _pmc_values(kernel=None):
+    """{kernel line -> bytes} from the committed PMC passes: counters are in KiB; FETCH_SIZE is doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (128-B requests tallied at 64 B),
+    WRITE_SIZE is exact.  None when the files are absent."""
+    per = {}
     for key, name in PMC_FILES.items():
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             return None
         for line in open(path):
-            if line.startswith(kernel) and key + "=" in line:
-                vals[key] = float(line.split(key + "=")[1].split()[0])
-    if len(vals) != 2:
+            if key + "=" in line and (kernel is None or line.startswith(kernel)):
+                per.setdefault(line.split("(")[0].split("<")[0].strip(), {})[key] = float(line.split(key + "=")[1].split()[0])
+    out = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in per.items() if len(v) == 2}
+    return out or None
+
+
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload (separate --pmc runs
+    of `bench.py --profile-step`).  A live run cannot collect counters on itself, so this is the profile of the same
+    command, not of this process; None when the files are absent."""
+    v = _pmc_values(kernel)
+    return None if not v else sum(v.values())
+
+
+def instep_ms(kernel: str):
+    """Average duration of `kernel` INSIDE the training step (cold L2, neighbours' tails) from the committed
+    rocprofv3 --kernel-trace --stats summary of `bench.py --profile-step` (profiles/<tag>_kernel_stats.csv); None if absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernel_stats.csv")
+    if not os.path.exists(path):
         return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    tot = None
+    for r in csv.DictReader(open(path)):
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if name.startswith(kernel):
+            tot = (tot or 0.0) + float(r["AverageNs"]) * 1e-6
+    return tot
 
 
 def event_ms(fn, reps):
@@ -138,9 +159,12 @@ def box_peaks(dev):
 
 def rooflines(trainer, n, opt, peak):
     """Per-kernel rooflines of one training step.  SIREN kernels against the MFMA peak with the
-    ALGORITHMIC flops of the layer they compute (not the flops executed: padding and the per-sample linear_lats GEMM count
-    as the reference's), K1 / K3 against HBM with the compulsory bytes per sample.  Each kernel timed alone, `reps`
-    launches back to back."""
+    ALGORITHMIC flops of what they compute (not the flops executed: padding counts as the reference's), the HBM-bound ones
+    (k_node_grad, K1, K3) against HBM with their compulsory bytes.  `avg_launch_ms`: the kernel timed alone here, `reps`
+    launches back to back, HIP events on the launch stream; `in_step_ms`: the same kernel inside the step, from the
+    committed rocprofv3 summary of this command (profiles/<tag>_kernel_stats.csv); `frac` uses the in-step time when
+    the profile is there (it is the one that adds up to the step), else the back-to-back one."""
+    import ctypes as C
     from cinema_amd import _lib
     from cinema_amd import engine as E
     eng, st = trainer.eng, trainer.store
@@ -152,59 +176,116 @@ def rooflines(trainer, n, opt, peak):
     bf16 = opt.precision == "bf16"
     coords, voxel, subj = st.coords[:n], st.voxel[:n], st.subj[:n]
     tfs, lat = trainer.tfs.data, trainer.latents.data
-    names = {"fwd": "k_fused_fwd", "chain": "k_fused_bwd", "dlat": "k_dlat256", "dw": "k_dw256"} if bf16 else \
-        {"fwd": "k_layer_fwd x layers + k_final_fwd", "chain": "k_layer_bwd x layers", "dlat": "k_dlat", "dw": "k_dw_grouped"}
-    siren = [
-        ("fwd", "forward stack incl. final_linear", 2 * mac_fwd, lambda: eng.forward(n)),
-        ("chain", "backward chain: dX of every layer", 2 * (mac_main + mac_first + H * od),
-         lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)),
-        ("dlat", "d-latent GEMM", 2 * (mac_mod + L * od), lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DLAT)),
-        ("dw", "all weight-gradient GEMMs" + (" (+ split reduction)" if bf16 else ""), 2 * mac_fwd,
-         lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW)),
-    ]
-    objs, tot_ms, tot_fl = [], 0.0, 0.0
-    for key, what, fl, fn in siren:
-        ms = event_ms(fn, reps)
-        ach = n * fl / (ms * 1e-3) / 1e12
-        objs.append({"kernel": f"{names[key]} ({what})", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                     "frac": ach / peak, "traffic": pmc_traffic(names[key]) if bf16 and n == 25000 else None,
-                     "avg_launch_ms": ms, "flop_per_sample": fl})
-        tot_ms += ms
-        tot_fl += n * fl
-    objs.sort(key=lambda o: -o["avg_launch_ms"])
-    agg = tot_fl / (tot_ms * 1e-3) / 1e12
-    siren_total = {"kernels": "SIREN fwd + bwd (the four above)", "flop_per_sample": 6 * mac_fwd, "ms": tot_ms,
-                   "achieved": agg, "peak": peak, "unit": "TFLOP/s", "frac": agg / peak}
+    S = lat.shape[0]
+    grouped = st.group_chunk > 0
+    use_ng = grouped and E.nodegrad_eligible(eng, tuple(lat.shape))
+    profiled = bf16 and n == 25000          # the committed profiles are of the default command
+
+    def obj(kernel, what, bound, work, unit_work, ms, names, executed=None):
+        ins = sum(filter(None, (instep_ms(k) for k in names))) if profiled else None
+        ins = ins or None
+        t = ins if ins else ms
+        ach = n * work / (t * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+        pk = peak if bound == "mfma" else HBM_PEAK_GBS
+        tr = [pmc_traffic(k) for k in names] if profiled else [None]
+        o = {"kernel": f"{kernel} ({what})", "bound": bound, "achieved": ach, "peak": pk, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+             "frac": ach / pk, "traffic": sum(tr) if all(x is not None for x in tr) else None, "avg_launch_ms": ms,
+             "in_step_ms": ins, "frac_from": "in_step_ms" if ins else "avg_launch_ms", unit_work: work}
+        if executed is not None:
+            o["flop_per_sample_executed"] = executed
+        return o
+
+    objs = []
+    if use_ng:
+        # the default path: chain kernels + node-space reductions (include/cinema_hip.h, "node gradients")
+        ng = trainer.ng
+        eng.pack(3 | 8)
+        E.k1_forward_sorted(eng, coords, subj, lat, None, tfs, n)
+        E.nodegrad_prepare(eng, ng, coords, subj, lat, None, tfs, n)
+        npad = E.round_up(n, 128)
+        lib = eng.lib
+        lib.cinema_debug_node_grad.argtypes = [C.POINTER(_lib.SirenDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                               C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lx, ly, lz = lat.shape[2:]
+        ng_args = dict(ng=ng, coords=coords, idx=subj, tfs=tfs, latents_shape=tuple(lat.shape), cond_dims=0,
+                       dlatents=trainer.lat_grad, dtfs=trainer.tf_grad, dcond=None)
+        F = n_mod * 2 * d.HP
+        node_rows = S * 32 / n          # node rows per sample row
+        ms = event_ms(lambda: eng.forward(n), reps)
+        objs.append(obj("k_fused_fwd", "forward stack incl. final_linear", "mfma", 2 * mac_fwd, "flop_per_sample", ms, ["k_fused_fwd"]))
+        ms = event_ms(lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN), reps)
+        objs.append(obj("k_fused_bwd", "backward chain: dX of every layer", "mfma", 2 * (mac_main + mac_first + H * od),
+                        "flop_per_sample", ms, ["k_fused_bwd"]))
+        ms = event_ms(lambda: eng.backward_nodegrad(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW,
+                                                    **ng_args), reps)
+        objs.append(obj("k_dw256 + k_ng_tail", "all weight-gradient GEMMs (linear_lats on S*32 node rows) + split reduction, table / "
+                        "embedding gradients", "mfma", 2 * mac_fwd, "flop_per_sample", ms, ["k_dw256", "k_ng_tail"],
+                        executed=2 * (mac_first + mac_main + H * od) + 2 * node_rows * (mac_mod + L * od)))
+        ms = event_ms(lambda: _lib.check(lib.cinema_debug_node_grad(C.byref(d), _lib.ptr(ng.work), _lib.ptr(ws.gbuf), _lib.ptr(ws.coords_t),
+                                                                     n, npad, S, lx, ly, lz, 0, _lib.ptr(eng.packed), _lib.ptr(eng.flat),
+                                                                     eng.stream()), "k_node_grad"), reps)
+        # what the d-latent GEMM + the K1 backward did per sample, now one pass over the ds / dt / dOut rows
+        node = obj("k_node_grad", "node-space reductions of ds / dt / dOut: dU, d coords through the interpolation, d node rows",
+                   "hbm", (F + 16) * 2, "bytes_per_sample", ms, ["k_node_grad"])
+        node["flop_per_sample"] = 2 * (mac_mod + L * od)                       # the algorithmic share it replaces (k_dlat's)
+        node["flop_per_sample_executed"] = 2 * 2 * 32 * F + 2 * node_rows * (F * L + L * od)
+        objs.append(node)
+    else:
+        names = {"fwd": "k_fused_fwd", "chain": "k_fused_bwd", "dlat": "k_dlat256", "dw": "k_dw256"} if bf16 else \
+            {"fwd": "k_layer_fwd x layers + k_final_fwd", "chain": "k_layer_bwd x layers", "dlat": "k_dlat", "dw": "k_dw_grouped"}
+        siren = [
+            ("fwd", "forward stack incl. final_linear", 2 * mac_fwd, lambda: eng.forward(n)),
+            ("chain", "backward chain: dX of every layer", 2 * (mac_main + mac_first + H * od),
+             lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)),
+            ("dlat", "d-latent GEMM", 2 * (mac_mod + L * od), lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DLAT)),
+            ("dw", "all weight-gradient GEMMs" + (" (+ split reduction)" if bf16 else ""), 2 * mac_fwd,
+             lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW)),
+        ]
+        for key, what, fl, fn in siren:
+            objs.append(obj(names[key], what, "mfma", fl, "flop_per_sample", event_ms(fn, reps), [names[key]] if bf16 else []))
+    tot_ms = sum(o["in_step_ms"] or o["avg_launch_ms"] for o in objs)
+    b2b_ms = sum(o["avg_launch_ms"] for o in objs)
+    agg = n * 6 * mac_fwd / (tot_ms * 1e-3) / 1e12
+    siren_total = {"kernels": "SIREN fwd + bwd (" + ", ".join(o["kernel"].split(" (")[0] for o in objs) + ")",
+                   "flop_per_sample": 6 * mac_fwd, "ms": tot_ms, "ms_back_to_back": b2b_ms, "achieved": agg, "peak": peak,
+                   "unit": "TFLOP/s", "frac": agg / peak}
+    chain = next(o for o in objs if o["kernel"].startswith("k_fused_bwd" if bf16 else "k_layer_bwd"))
+    mfma_objs = sorted((o for o in objs if o["bound"] == "mfma"), key=lambda o: -(o["in_step_ms"] or o["avg_launch_ms"]))
+    objs = mfma_objs + [o for o in objs if o["bound"] != "mfma"]
     # HBM view of the dominant kernel: the bytes are the saved-activation traffic this design chose, not compulsory ones
     esize = 2 if bf16 else 4
-    chain = next(o for o in objs if o["kernel"].startswith(names["chain"]))
     tensors = 2 * d.n_layers + 4 * n_mod                            # c + dz per layer; z, s, ds, dt per modulated layer
     bps = tensors * d.HP * esize + 4 * (od + 2 * ind)
+    t_chain = chain["in_step_ms"] or chain["avg_launch_ms"]
     hbm_view = {"kernel": chain["kernel"], "bound": "hbm", "bytes": "saved-activation traffic of this design",
-                "achieved": n * bps / (chain["avg_launch_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": n * bps / (t_chain * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "bytes_per_sample": bps, "traffic": chain["traffic"]}
     hbm_view["frac"] = hbm_view["achieved"] / HBM_PEAK_GBS
     # K1 / K3: compulsory bytes per sample (the interpolated latent leaves K1 in the activation dtype)
     cl = d.lat * esize
-    grouped = st.group_chunk > 0
     k1f = (lambda: E.k1_forward_sorted(eng, coords, subj, lat, None, tfs, n)) if grouped and E.k1_sorted_eligible(tuple(lat.shape), d.LP) \
         else (lambda: E.k1_forward(eng, trainer.k1, coords, subj, lat, None, tfs, False, n))
-    k1b = lambda: E.k1_backward(eng, trainer.k1, coords, subj, tuple(lat.shape), 0, tfs, False, n, want_latents=True,
-                                want_cond=False, dtf_out=trainer.tf_grad, dlat_out=trainer.lat_grad, grouped=grouped)
     k3 = lambda: E.sample_loss(None, ws.out, n, trainer.sr_dims, trainer.n_cls, trainer.loss_metric, trainer.class_w, 1.0, 1.0,
                                ws.dout, trainer.sums, voxel=voxel, subj=subj, intens=st.intens, labels=st.labels,
                                voxels_per_subject=st.V, prepared=True)
-    E.k1_shadow(eng, trainer.k1, lat)
+    legs = [("K1 forward (affine + trilinear gather; in the step it is a block range of k_step_head)", 12 + 4 + cl, k1f, ["k_step_head"]),
+            ("K3 (ground-truth sampling + loss + dOut)", 4 * od + 4 * trainer.sr_dims + 1 + 4 + 4 * od + 1, k3, ["k_sample_loss"])]
+    if not use_ng:
+        E.k1_shadow(eng, trainer.k1, lat)
+        k1b = lambda: E.k1_backward(eng, trainer.k1, coords, subj, tuple(lat.shape), 0, tfs, False, n, want_latents=True,
+                                    want_cond=False, dtf_out=trainer.tf_grad, dlat_out=trainer.lat_grad, grouped=grouped)
+        legs.insert(1, ("K1 backward (coordinate gradient + latent / tf reductions)", 4 * d.lat + 12 + 4, k1b, []))
     hbm = []
-    for name, bytes_ps, fn in (("K1 forward (affine + trilinear gather)", 12 + 4 + cl, k1f),
-                               ("K1 backward (coordinate gradient + latent / tf reductions)", 4 * d.lat + 12 + 4, k1b),
-                               ("K3 (ground-truth sampling + loss + dOut)", 4 * od + 4 * trainer.sr_dims + 1 + 4 + 4 * od + 1, k3)):
+    for name, bytes_ps, fn, prof_names in legs:
         ms = event_ms(fn, reps)
         ach = n * bytes_ps / (ms * 1e-3) / 1e9
+        ins = sum(filter(None, (instep_ms(k) for k in prof_names))) if profiled else None
         hbm.append({"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "avg_launch_ms": ms, "bytes_per_sample": bytes_ps})
+                    "avg_launch_ms": ms, "in_step_ms": ins or None, "bytes_per_sample": bytes_ps})
     trainer.lat_grad.zero_()
     trainer.tf_grad.zero_()
+    eng.flat_grad.zero_()
+    eng.grads_clean = True
 
     def optimiser():
         trainer.opt_local.step()
@@ -214,8 +295,28 @@ def rooflines(trainer, n, opt, peak):
     return objs, siren_total, hbm_view, hbm, opt_ms
 
 
-def run_atlas(opt, dev):
+def step_profile_summary(n):
+    """Whole-step figures of the committed profile of this command: kernels of one step with their in-step durations and
+    HBM-side bytes (PMC), their sums, bytes per sample."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernel_stats.csv")
+    traffic = _pmc_values()
+    if not os.path.exists(path) or traffic is None:
+        return None
+    rows = []
+    for r in csv.DictReader(open(path)):
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].strip()
+        if name.startswith("k_") and int(r["Calls"]) >= 20:         # launched every step (the profile run has 25 steps)
+            rows.append({"kernel": name, "in_step_ms": float(r["AverageNs"]) * 1e-6, "traffic": traffic.get(name)})
+    tot_b = sum(x["traffic"] or 0.0 for x in rows)
+    return {"source": f"profiles/{PROFILE_TAG}_kernel_stats.csv, {PROFILE_TAG}_pmc_fetch.txt, {PROFILE_TAG}_pmc_write.txt",
+            "kernels": rows, "kernel_ms_sum": sum(x["in_step_ms"] for x in rows), "hbm_bytes_per_step": tot_b,
+            "hbm_bytes_per_sample": tot_b / n}
+
+
+def atlas_measure(opt, dev, steps, warmup, chunk):
     """BASELINE config 4 (cfg-A): one dense 310^3 volume (29.8 M coordinates at 0.5 mm) through INR_Decoder.inference."""
+    from cinema_amd import engine as E
     from cinema_amd.models.inr_decoder import INR_Decoder
     from cinema_amd.utils import generate_world_grid
     args = make_args(512, opt.precision, opt.loss, opt.n_samples)
@@ -228,38 +329,95 @@ def run_atlas(opt, dev):
     cond = torch.zeros(0, device=dev)
     grid, shape, _ = generate_world_grid(args, device=dev, lazy=True)
     G = len(grid)
-    for _ in range(opt.warmup):
-        vol = dec.inference(grid, lat, cond, shape, None, step_size=opt.chunk)
+    for _ in range(warmup):
+        vol = dec.inference(grid, lat, cond, shape, None, step_size=chunk)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(opt.steps):
-        vol = dec.inference(grid, lat, cond, shape, None, step_size=opt.chunk)
+    for _ in range(steps):
+        vol = dec.inference(grid, lat, cond, shape, None, step_size=chunk)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert tuple(vol.shape) == (shape[0], shape[1], shape[2], 13) and bool(torch.isfinite(vol[..., 2:]).all())
+    del vol
     eng = dec.sr_net.hot_state(dev).engine
-    m = min(max(opt.chunk, dec.min_inference_chunk), G)
-    from cinema_amd import engine as E
+    d = eng.desc
+    m = min(max(chunk, dec.min_inference_chunk) if eng.can_skip_saved() else chunk, G)
     nodes = E.nodes_inference_eligible(eng, (1, 256, 3, 3, 3))
     idx0 = torch.zeros(m, dtype=torch.int32, device=dev)
+    eng.workspace(m)
     ms = event_ms((lambda: eng.forward_nodes(m, dec._nodes, idx0, keep=False)) if nodes else (lambda: eng.forward(m, keep=False)),
                   opt.kernel_reps)
     fwd_f, _ = flops_per_sample()
+    # flops the nodes kernel executes: the per-sample linear_lats GEMM (lat x 2H per modulated layer) and the latent columns
+    # of final_linear are one k = 32 step over the node projections each
+    H, L, od = d.hidden, d.lat, d.out_dim
+    n_mod = bin(d.modulated_mask).count("1")
+    exec_f = 2 * (d.in_dim * H + (d.n_layers - 1) * H * H + n_mod * 32 * 2 * H + (H + 32) * od) if nodes else fwd_f
     peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     ach = m * fwd_f / (ms * 1e-3) / 1e12
-    value = opt.steps * G / elapsed
-    res = {"metric": "atlas coords/sec, dense inference (hidden 512)", "value": value, "unit": "coords/s", "n_gpus": 1,
-           "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
+    value = steps * G / elapsed
+    kern = (("k_nodes_fwd" if nodes else "k_fused_fwd") + ", nothing kept (one chunk)") if opt.precision == "bf16" else "k_layer_fwd x layers"
+    return {"value": value, "unit": "coords/s", "ms_per_volume": elapsed / steps * 1e3, "volumes_timed": steps, "warmup": warmup,
+            "shape": shape, "coords": G, "spacing_mm": sp, "step_size": chunk, "chunk": m, "dtype": opt.precision,
+            "end_to_end_mfma_tflops": value * fwd_f / 1e12, "end_to_end_mfma_frac": value * fwd_f / 1e12 / peak,
+            "roofline": {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "frac_executed": m * exec_f / (ms * 1e-3) / 1e12 / peak, "traffic": None, "avg_launch_ms": ms,
+                         "flop_per_sample": fwd_f, "flop_per_sample_executed": exec_f}}
+
+
+def run_atlas(opt, dev):
+    a = atlas_measure(opt, dev, opt.steps, opt.warmup, opt.chunk)
+    shape, G = a["shape"], a["coords"]
+    res = {"metric": "atlas coords/sec, dense inference (hidden 512)", "value": a["value"], "unit": "coords/s", "n_gpus": 1,
+           "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": a["ms_per_volume"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic",
-           "config": {"workload": f"cfg-A: one {shape[0]}x{shape[1]}x{shape[2]} volume ({G:,} coordinates, spacing {sp:.3f} mm) "
-                                  f"through INR_Decoder.inference(step_size={opt.chunk}), evaluated in chunks of "
-                                  f"{min(max(opt.chunk, dec.min_inference_chunk), G)}: grid coordinates made per chunk, "
-                                  "K1, SIREN forward (nothing kept), fused clamp / min-max / argmax / softmax epilogue, rescale"},
-           "end_to_end_mfma_tflops": value * fwd_f / 1e12, "end_to_end_mfma_frac": value * fwd_f / 1e12 / peak,
-           "roofline": {"kernel": ("k_nodes_fwd" if nodes else "k_fused_fwd") + ", nothing kept (one chunk)" if opt.precision == "bf16" else "k_layer_fwd x layers",
-                        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                        "avg_launch_ms": ms, "flop_per_sample": fwd_f}}
+           "config": {"workload": f"cfg-A: one {shape[0]}x{shape[1]}x{shape[2]} volume ({G:,} coordinates, spacing {a['spacing_mm']:.3f} mm) "
+                                  f"through INR_Decoder.inference(step_size={opt.chunk}), evaluated in chunks of {a['chunk']}: grid "
+                                  "coordinates made per chunk, K1, SIREN forward (nothing kept), fused clamp / min-max / argmax / "
+                                  "softmax epilogue, rescale"},
+           "end_to_end_mfma_tflops": a["end_to_end_mfma_tflops"], "end_to_end_mfma_frac": a["end_to_end_mfma_frac"],
+           "roofline": a["roofline"]}
     print(json.dumps(res))
+
+
+def data_parallel_report(trainer, opt, dev, world, rank, n, total_steps, barrier, ms_per_step):
+    """What makes a multi-GPU line auditable (collective): the collective library actually in use, the gradient
+    all-reduce timed alone, and how much of it the step does NOT hide (step time minus step time with the collective
+    switched off, CINEMA_DP_SKIP_ALLREDUCE=1 -- measurement only, the replicas drift apart afterwards, so it runs last)."""
+    import torch.distributed as dist
+    from cinema_amd import parallel as par
+    backend = dist.get_backend()
+    names = [None] * world
+    dist.all_gather_object(names, torch.cuda.get_device_name(dev) + f" (cuda:{dev.index})")
+    info = {"backend": backend, "world_size": dist.get_world_size(), "devices": names,
+            "library_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None}
+    g = trainer.eng.flat_grad
+    reps = 20
+    par.allreduce_mean_(g, trainer.pg)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        par.allreduce_mean_(g, trainer.pg)
+    barrier()
+    ar_ms = (time.perf_counter() - t0) / reps * 1e3
+    g.zero_()
+    trainer.eng.grads_clean = True
+    os.environ["CINEMA_DP_SKIP_ALLREDUCE"] = "1"
+    lo = total_steps - opt.steps                      # the same samples as the timed steps
+    for i in range(lo, lo + min(3, opt.steps)):
+        trainer.step(i * n, (i + 1) * n)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(lo, total_steps):
+        trainer.step(i * n, (i + 1) * n)
+    barrier()
+    skip = time.perf_counter() - t0
+    del os.environ["CINEMA_DP_SKIP_ALLREDUCE"]
+    t = torch.tensor([skip, ar_ms], device="cpu" if backend != "nccl" else dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    skip_ms = float(t[0]) / opt.steps * 1e3
+    return {"rccl": info, "allreduce_bytes": g.numel() * 4, "allreduce_ms": float(t[1]),
+            "ms_per_step_without_allreduce": skip_ms, "allreduce_exposed_ms": ms_per_step - skip_ms}
 
 
 def main():
@@ -273,6 +431,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default="mse", choices=["mse", "l1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-atlas", action="store_true", help="train mode: leave out the \"atlas\" object (one 310^3 volume, ~1 s)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--mode", default="train", choices=["train", "atlas"],
                     help="train: the headline training step (default); atlas: one dense 310^3 volume through inference (cfg-A)")
@@ -363,6 +522,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = trainer.loss_dict()
+    dp = None
+    if world > 1:
+        dp = data_parallel_report(trainer, opt, dev, world, rank, n, total_steps, barrier, elapsed / opt.steps * 1e3)
 
     peak = MFMA_BF16_PEAK_TFLOPS if opt.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     siren = siren_total = hbm_view = hbm = peaks = opt_ms = None
@@ -370,6 +532,9 @@ def main():
         siren, siren_total, hbm_view, hbm, opt_ms = rooflines(trainer, n, opt, peak)
         peaks = box_peaks(dev)
 
+    cpu_baseline_obj = None
+    if rank == 0 and world == 1 and not opt.no_cpu_baseline and not opt.profile_step:
+        cpu_baseline_obj = cpu_baseline(args, trainer, n, lat0, tf0, flat0)
     fwd_f, tot_f = flops_per_sample()
     value = world * opt.steps * n / elapsed
     step_tflops = value * tot_f / 1e12
@@ -395,8 +560,16 @@ def main():
             ms = res["ms_per_step"]
             res["optimiser_ms"] = opt_ms                     # the fused AdamW launch(es), timed alone
             res["value_without_optimiser"] = world * n / ((ms - opt_ms) * 1e-3)
+            res["step_profile"] = step_profile_summary(n) if (opt.precision == "bf16" and n == 25000) else None
+        if dp is not None:
+            res.update(dp)
+        if world == 1 and not opt.profile_step and not opt.no_atlas:
+            # BASELINE config 4 beside the headline: one 310^3 volume, 1 warm-up + 2 timed (0.3 s)
+            del trainer
+            torch.cuda.empty_cache()
+            res["atlas"] = atlas_measure(opt, dev, 2, 1, opt.chunk)
         if world == 1 and not opt.no_cpu_baseline and not opt.profile_step:
-            res["cpu_baseline"] = cpu_baseline(args, trainer, n, lat0, tf0, flat0)
+            res["cpu_baseline"] = cpu_baseline_obj
         print(json.dumps(res))
     if world > 1:
         dist.barrier()              # rank 0 times single kernels after the steps: leave together

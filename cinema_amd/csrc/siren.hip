@@ -1339,7 +1339,6 @@ extern "C" int cinema_siren_backward_nodegrad(const cinema_siren_desc *d, const 
                  "cinema_siren_backward_nodegrad: needs a bf16 stack on the activation-stationary path (hidden <= 512) with a "
                  "modulated layer and a latent grid of at most %d nodes", NG_ONE_SLOT - 1);
   CINEMA_REQUIRE((flags & CINEMA_BWD_SKIP_WEIGHT_GRADS) || grad_params, "cinema_siren_backward_nodegrad: grad_params is null");
-  CINEMA_REQUIRE(!(flags & CINEMA_BWD_PHASE_MASK), "cinema_siren_backward_nodegrad: no phase selection on this entry point");
   CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0 && S >= 1, "cinema_siren_backward_nodegrad: need 1 <= N <= Npad, Npad %% 128 == 0, S >= 1");
   CINEMA_REQUIRE(C >= 1 && C + cond_dims == d->lat, "cinema_siren_backward_nodegrad: C + cond_dims = %d != lat_size %d", C + cond_dims, d->lat);
   CINEMA_REQUIRE(dembed == nullptr || (embed != nullptr && (tf_dim == 6 || tf_dim == 9 || tf_dim == 12)),

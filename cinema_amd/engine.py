@@ -223,7 +223,7 @@ class SirenEngine:
     def backward_nodegrad(self, n: int, dout_padded: torch.Tensor, ng: "NodeGrad", coords: torch.Tensor, idx: torch.Tensor,
                           tfs: Optional[torch.Tensor], latents_shape, cond_dims: int, dlatents: torch.Tensor,
                           dtfs: Optional[torch.Tensor], dcond: Optional[torch.Tensor], weight_grads: bool = True,
-                          dcoords_cleared: bool = False, part: int = 0):
+                          dcoords_cleared: bool = False, part: int = 0, phases: int = 0):
         """SIREN backward + K1 backward in one call with the latent side reduced in node space (include/cinema_hip.h,
         "node gradients"): fills flat_grad, dlatents (S, C, lx, ly, lz), dtfs (S, tf_dim), dcond (S, cond_dims).
         The batch must be grouped by subject and nodegrad_prepare must have run on the current parameters."""
@@ -231,11 +231,11 @@ class SirenEngine:
         ws.ensure_backward()
         npad = round_up(n, ROW_ALIGN)
         S, Cc, lx, ly, lz = latents_shape
-        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | part
+        flags = (0 if weight_grads else _lib.BWD_SKIP_WEIGHT_GRADS) | part | phases     # phases: single kernels (bench.py)
         if dcoords_cleared:
             flags |= _lib.BWD_DCOORDS_CLEARED
         if weight_grads and part != _lib.BWD_DLAT_ONLY:
-            if self.grads_clean:
+            if self.grads_clean and phases == 0:
                 flags |= _lib.BWD_GRADS_CLEARED
             self.grads_clean = False
         check(self.lib.cinema_siren_backward_nodegrad(

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -57,6 +59,8 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group=None, async_op: bool 
     _, world = world_info(process_group)
     if world == 1:
         return None
+    if os.environ.get("CINEMA_DP_SKIP_ALLREDUCE") == "1":
+        return None      # MEASUREMENT ONLY (bench.py allreduce_exposed_ms): the replicas drift apart from here on
     backend = dist.get_backend(process_group)
     if backend == "nccl":
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=process_group, async_op=async_op)

@@ -356,7 +356,9 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
  *     table (`latents` (S, C, lx, ly, lz): the table K1 interpolates; cond_subject [S x cond_dims] or NULL).
  *     flags & 1: cinema_step_head already wrote the node rows of this table into `work` (one launch instead of two).
  *   cinema_siren_backward_nodegrad: flags as cinema_siren_backward (SKIP_WEIGHT_GRADS, GRADS_CLEARED, DCOORDS_CLEARED,
- *     WEIGHTS_FIRST / DLAT_ONLY: the first call leaves grad_params complete, the second one the table-side gradients).
+ *     WEIGHTS_FIRST / DLAT_ONLY: the first call leaves grad_params complete, the second one the table-side gradients;
+ *     the PHASE bits time single stages on whatever earlier stages left in the buffers: CHAIN = chain kernel +
+ *     k_node_grad, DW = weight-gradient launch + tail, DLAT = the table-side tail alone).
  *     Outputs (overwritten): grad_params, dlatents (S, C, lx, ly, lz), dembed [S x tf_dim] or NULL, dcond [S x cond_dims]
  *     or NULL (per-SUBJECT condition gradient).  dcoords [Npad x 3] holds the first layer's part only.
  * ------------------------------------------------------------------------------------- */
