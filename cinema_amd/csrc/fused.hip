@@ -434,7 +434,7 @@ struct FusedBwdArgs {
   float om_first, om_hidden;
 };
 
-template <bool MOD, bool FIRST, int NST, bool FP8>
+template <bool MOD, bool FIRST, int NST, bool FP8, bool LATB>
 __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)[4][NST], int l, float omega, long n0,
                                              unsigned toff_l, unsigned tstep, unsigned fb_l, int i_l, int g, int lane,
                                              lds_char *gs, const lds_char *w0s, const lds_char *cs) {
@@ -495,7 +495,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
               ds[j] = omega * gq * zj;
             }
           }
-          if (a.latb) {
+          if constexpr (LATB) {      // compiled out when the node-space reductions take the linear_lats bias sums
             ts += reduce16_scatter(ds, lane);
             tt += reduce16_scatter(dt, lane);
           }
@@ -556,7 +556,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
         const int fi = fb_l + reduce16_index(i_l);
         if (fi < a.H) atomicAdd(a.gp + a.off_b[l] + fi, tz);
         if constexpr (MOD) {
-          if (fi < a.H && a.latb) {
+          if (fi < a.H && LATB) {
             atomicAdd(a.gp + a.off_bl[l] + fi, ts);
             atomicAdd(a.gp + a.off_bl[l] + a.H + fi, tt);
           }
@@ -570,7 +570,7 @@ __device__ __forceinline__ void bwd_epilogue(const FusedBwdArgs &a, f32x4 (&acc)
       }
 }
 
-template <int NST, bool FP8>
+template <int NST, bool FP8, bool LATB>
 __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long n0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char *gs = (lds_char *)smem;                       // g tile [64][xrow] bf16, swizzled
@@ -643,24 +643,24 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs &a, const long
     __syncthreads();  // every wave has finished reading g
     if (active) {
       if (l == 0) {
-        if (mod) bwd_epilogue<true, true, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, true, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, true, NST, FP8, LATB>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, true, NST, FP8, LATB>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       } else {
-        if (mod) bwd_epilogue<true, false, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
-        else bwd_epilogue<false, false, NST, FP8>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        if (mod) bwd_epilogue<true, false, NST, FP8, LATB>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
+        else bwd_epilogue<false, false, NST, FP8, LATB>(a, acc, l, omega, n0, toff_l, tstep, fb_l, i_l, g, lane, gs, w0s, cs);
       }
     }
     __syncthreads();  // g of the next (lower) layer is complete
   }
 }
 
-template <bool FP8>
+template <bool FP8, bool LATB>
 __global__ __launch_bounds__(512) void k_fused_bwd(FusedBwdArgs a) {
   // behind the chain workgroups: the dOut preparation of the weight-gradient launch (reads dOut only; these workgroups
   // land on the CUs the shorter second round leaves idle)
   if ((int)blockIdx.x >= a.g_chain) { dout_prep_body<bf16_t>(a.fin, a.dout16, blockIdx.x - a.g_chain, a.g_fin); return; }
-  if ((int)blockIdx.x < a.g4) fused_bwd_body<4, FP8>(a, 64L * blockIdx.x);
-  else fused_bwd_body<3, FP8>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
+  if ((int)blockIdx.x < a.g4) fused_bwd_body<4, FP8, LATB>(a, 64L * blockIdx.x);
+  else fused_bwd_body<3, FP8, LATB>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
 
 }  // namespace
@@ -930,13 +930,18 @@ int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const f
     a.dout16 = (bf16_t *)dout16;
     a.g_fin = (int)std::min<int64_t>((Npad + 511) / 512, 128);
   }
+  const dim3 grid((unsigned)(a.g_chain + a.g_fin));
+#define FUSED_BWD_LAUNCH(FP8, LATB)                                                            \
+  do {                                                                                         \
+    CINEMA_SMEM_ATTR((k_fused_bwd<FP8, LATB>), smem);                                          \
+    hipLaunchKernelGGL((k_fused_bwd<FP8, LATB>), grid, dim3(512), smem, s, a);                 \
+  } while (0)
   if (fused_saved_fp8()) {
-    CINEMA_SMEM_ATTR(k_fused_bwd<true>, smem);
-    hipLaunchKernelGGL(k_fused_bwd<true>, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
+    if (a.latb) FUSED_BWD_LAUNCH(true, true); else FUSED_BWD_LAUNCH(true, false);
   } else {
-    CINEMA_SMEM_ATTR(k_fused_bwd<false>, smem);
-    hipLaunchKernelGGL(k_fused_bwd<false>, dim3((unsigned)(a.g_chain + a.g_fin)), dim3(512), smem, s, a);
+    if (a.latb) FUSED_BWD_LAUNCH(false, true); else FUSED_BWD_LAUNCH(false, false);
   }
+#undef FUSED_BWD_LAUNCH
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
 }
