@@ -92,6 +92,7 @@ SIGNATURES = {
                                     _I32, _P, _P],
     "cinema_nodegrad_eligible": [C.POINTER(SirenDesc), _I32, _I32, _I32],
     "cinema_nodegrad_work_bytes": [C.POINTER(SirenDesc), _I64, _I64],
+    "cinema_siren_forward_node_prep": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "cinema_nodegrad_prepare": [C.POINTER(SirenDesc), _P, _P, _P, _P, _I32, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32,
                                 _P, _I32, _P],
     "cinema_siren_backward_nodegrad": [C.POINTER(SirenDesc), _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _I32,

@@ -17,7 +17,9 @@ bool fused_eligible(const cinema_siren_desc *d);
 void fused_plan(cinema_siren_desc *d, long *pk);                   // appends the stream regions to the packed layout
 int fused_pack(const cinema_siren_desc *d, const float *params, void *packed, hipStream_t s);
 int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
-                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s);
+                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s, void *node_work = nullptr,
+                  int64_t node_S = 0);
+// node_work != NULL: the node projections of the node-space backward (nodegrad.h) ride as tail workgroups of the launch
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
                          hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr, bool lat_bias = true);

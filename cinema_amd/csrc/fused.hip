@@ -18,6 +18,7 @@ namespace {
 #include "k1_device.h"
 #include "step_device.h"
 #include "noderows_device.h"
+#include "ngprep_device.h"
 #include "dw_device.h"
 
 inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
@@ -140,15 +141,15 @@ __global__ __launch_bounds__(256) void k_pack_side(PackSideArgs a) { pack_side_b
 // shadow of the latent table and the per-step clearing are independent, but as separate kernels they either share a
 // stream (23 + 17 us in a row for the two the forward waits for) or need a second stream, whose join costs 6-10 us of
 // idle queue.  Block ranges: step_prepare (the longest chain of dependent loads; optional, g_pr = 0) | K1 forward chunks |
-// backward-only transposes (64 workgroups each) | weight streams | side block | node rows of the node-space backward
-// (optional, g_nr = 0) | shadow tiles (optional, g_nm = 0).
+// backward-only transposes (64 workgroups each) | weight streams | side block | node rows and interpolation weights of the
+// node-space backward (optional, g_nr = g_ngw = 0) | shadow tiles (optional, g_nm = 0).
 #define HEAD_MAX_JOBS 16
 struct StepHeadArgs {
   PackStreamArgs ps; PackSideArgs sd; TriFwdSortedArgs k1;
   PackJob job[HEAD_MAX_JOBS]; void *packed;
   const float *nm_lat; float *nm_shadow; long nm_S; int nm_C, nm_G;
-  StepPrepareArgs pr; NodeRowsCArgs nr;
-  int g_k1, g_ps, g_sd, g_job, g_nm, g_pr, g_nr;
+  StepPrepareArgs pr; NodeRowsCArgs nr; NgWeightArgs ngw;
+  int g_k1, g_ps, g_sd, g_job, g_nm, g_pr, g_nr, g_ngw;
 };
 __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   int b = blockIdx.x;                            // workgroup-uniform dispatch; the longest dependent-load chains first
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   b -= a.g_pr;
   if (b < a.g_k1) { trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b); return; }
   b -= a.g_k1;
+  if (b < a.g_ngw) {                             // dependent loads (idx -> embedding row) like K1: early
+    __shared__ float ct[16 * NG_WB][4];
+    ng_weights_body<256>(a.ngw, b, ct);
+    return;
+  }
+  b -= a.g_ngw;
   if (b < a.g_job) { pack_job_body<bf16_t>(a.job[b >> 6], a.packed, b & 63, 64); return; }
   b -= a.g_job;
   if (b < a.g_ps) { pack_stream_body(a.ps, b, a.g_ps); return; }
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   b -= a.g_sd;
   if (b < a.g_nr) { node_rows_centred_body(a.nr, b); return; }
   b -= a.g_nr;
+
   node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
 }
 
@@ -196,6 +204,7 @@ struct FusedFwdArgs {
   int lb_b[CINEMA_MAX_LAYERS], lb_bl[CINEMA_MAX_LAYERS], lb_total;   // LDS side block: float offsets
   const float *side;
   int trace_block, trace_wave;
+  NgProjArgs proj; int g_chain;      // tail workgroups [g_chain, grid): node projections of the node-space backward
 };
 
 // NST = sample tiles of 16 per workgroup: 4 (64 samples) or 3 (48: the second, shorter round of a batch that fills the
@@ -408,6 +417,13 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs &a, const long
 
 template <bool FP8>
 __global__ __launch_bounds__(512) void k_fused_fwd(FusedFwdArgs a) {
+  if ((int)blockIdx.x >= a.g_chain) {
+    // behind the chain workgroups: U' / V' of the backward's node reductions (they read the packed weights and the centred
+    // node rows of the step head only; these workgroups land on the CUs the shorter second round leaves idle)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ng_project_body(a.proj, (int)blockIdx.x - a.g_chain, (lds_char *)smem);
+    return;
+  }
   if ((int)blockIdx.x < a.g4) fused_fwd_body<4, FP8>(a, 64L * blockIdx.x);
   else fused_fwd_body<3, FP8>(a, 64L * a.g4 + 48L * ((int)blockIdx.x - a.g4));
 }
@@ -801,10 +817,13 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
   if (node_work != nullptr) {                  // T and Tc of the node-space backward (cinema_nodegrad_prepare, flags & 1)
     CINEMA_REQUIRE(cond_by_subject || cond_dims == 0, "cinema_step_head: node rows need per-subject conditions");
     CINEMA_REQUIRE(ng_eligible(d, lx, ly, lz) && d->LP % 32 == 0, "cinema_step_head: node rows need a stack cinema_nodegrad_eligible accepts");
-    const NgPlan p = ng_plan(d, S, 128);       // the places of T and Tc do not depend on Npad
+    CINEMA_REQUIRE(Npad % 128 == 0, "cinema_step_head: node tables need Npad %% 128 == 0");
+    const NgPlan p = ng_plan(d, S, Npad);      // the same plan cinema_nodegrad_work_bytes(d, S, Npad) sized the buffer with
     a.nr = NodeRowsCArgs{latents, cond, (long)S, C, lx * ly * lz, cond_dims, d->LP, (bf16_t *)((char *)node_work + p.T),
                          (bf16_t *)((char *)node_work + p.Tc)};
     a.g_nr = (int)(S * (d->LP / 32));
+    a.ngw = ng_weight_args(p, node_work, coords, idx, embed, tf_dim, (long)N, lx, ly, lz);
+    a.g_ngw = ng_weight_grid(p);
   }
   if (sums != nullptr) {
     CINEMA_REQUIRE(scratch != nullptr && n_dcoords >= 0 && (dcoords != nullptr || n_dcoords == 0), "cinema_step_head: bad prepare arguments");
@@ -813,7 +832,7 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
     a.g_pr = (int)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
     a.pr = StepPrepareArgs{dcoords, (long)n_dcoords, sums, voxel, idx, labels, (long)V, (long)N, n_cls, class_w, scratch};
   }
-  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nr + a.g_nm + a.g_pr)), dim3(256), 0,
+  hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nr + a.g_ngw + a.g_nm + a.g_pr)), dim3(256), 0,
                      (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -859,7 +878,8 @@ static void fused_launch_plan(int64_t Npad, int *g4, int *g3) {
 }
 
 int fused_forward(const cinema_siren_desc *d, const float *params, const void *packed, const float *coords_t,
-                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s) {
+                  const void *lat, int64_t N, int64_t Npad, void *saved, float *out, hipStream_t s, void *node_work,
+                  int64_t node_S) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_fs >= 0, "fused_forward: descriptor not planned for the fused path");
   CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_forward: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
   FusedFwdArgs a = {};
@@ -887,12 +907,22 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
   const int smem = fused_lds_bytes(d);
   int g3;
   fused_launch_plan(Npad, &a.g4, &g3);
+  a.g_chain = a.g4 + g3;
+  long g_proj = 0;
+  if (node_work != nullptr) {
+    CINEMA_REQUIRE(Npad % 128 == 0 && node_S >= 1, "fused_forward: node projections need Npad %% 128 == 0 and S >= 1");
+    const NgPlan p = ng_plan(d, node_S, Npad);
+    CINEMA_REQUIRE(ng_proj_smem(d) <= smem, "fused_forward: node projections need %d bytes of LDS, the forward has %d", ng_proj_smem(d), smem);
+    a.proj = ng_proj_args(d, p, node_work, packed);
+    g_proj = ng_proj_grid(p);
+    CINEMA_REQUIRE(a.g_chain + g_proj < (1L << 30), "fused_forward: too many subjects");
+  }
   if (fused_saved_fp8()) {
     CINEMA_SMEM_ATTR(k_fused_fwd<true>, smem);
-    hipLaunchKernelGGL(k_fused_fwd<true>, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+    hipLaunchKernelGGL(k_fused_fwd<true>, dim3((unsigned)(a.g_chain + g_proj)), dim3(512), smem, s, a);
   } else {
     CINEMA_SMEM_ATTR(k_fused_fwd<false>, smem);
-    hipLaunchKernelGGL(k_fused_fwd<false>, dim3((unsigned)(a.g4 + g3)), dim3(512), smem, s, a);
+    hipLaunchKernelGGL(k_fused_fwd<false>, dim3((unsigned)(a.g_chain + g_proj)), dim3(512), smem, s, a);
   }
   CINEMA_CHECK_HIP(hipGetLastError());
   (void)N;

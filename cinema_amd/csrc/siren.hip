@@ -1013,6 +1013,19 @@ extern "C" int cinema_siren_forward(const cinema_siren_desc *d, const float *par
              : forward_impl<float>(d, params, packed, coords_t, lat, N, Npad, saved, out, s);
 }
 
+extern "C" int cinema_siren_forward_node_prep(const cinema_siren_desc *d, const float *params, const void *packed,
+                                              const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved,
+                                              float *out, void *node_work, int64_t S, int32_t lx, int32_t ly, int32_t lz,
+                                              void *stream) {
+  CINEMA_REQUIRE(d && params && packed && coords_t && lat && out && node_work, "cinema_siren_forward_node_prep: null argument");
+  CINEMA_REQUIRE(fused_mode(d) == 64 && ng_eligible(d, lx, ly, lz),
+                 "cinema_siren_forward_node_prep: needs a stack cinema_nodegrad_eligible accepts (bf16 chain kernels)");
+  CINEMA_REQUIRE(N >= 1 && Npad >= N && Npad % 128 == 0 && S >= 1,
+                 "cinema_siren_forward_node_prep: need 1 <= N <= Npad, Npad %% 128 == 0, S >= 1 (N=%ld Npad=%ld S=%ld)", (long)N,
+                 (long)Npad, (long)S);
+  return fused_forward(d, params, packed, coords_t, lat, N, Npad, saved, out, (hipStream_t)stream, node_work, S);
+}
+
 template <typename T, bool MOD, bool SMALLK, bool FIRST>
 static int launch_bwd(const BwdArgs &a, int grid, hipStream_t s) {
   constexpr int smem = Engine<T>::NT_SMEM;

@@ -155,13 +155,22 @@ class SirenEngine:
         """True when a forward may run without keeping activations (the activation-stationary bf16 kernels)."""
         return self.desc.pk_fs >= 0 and os.environ.get("CINEMA_SIREN_LAYERED") != "1"
 
-    def forward(self, n: int, keep: bool = True) -> torch.Tensor:
+    def forward(self, n: int, keep: bool = True, ng: Optional["NodeGrad"] = None, latents_shape=None) -> torch.Tensor:
         """Run the stack on ws.coords_t / ws.lat (already filled for n rows). Returns ws.out.
-        keep=False (inference): nothing is saved for a backward where the kernels allow it."""
+        keep=False (inference): nothing is saved for a backward where the kernels allow it.
+        ng (with latents_shape): the node projections of the node-space backward ride in the same launch
+        (cinema_siren_forward_node_prep; step_head(..., ng=ng) of this step wrote the node rows and weights)."""
         ws = self.ws
         npad = round_up(n, ROW_ALIGN)
         self.version += 1
         saved = ws.saved if (keep or not self.can_skip_saved()) else None
+        if ng is not None:
+            S, _, lx, ly, lz = latents_shape
+            ng.ensure(self, S, npad)
+            check(self.lib.cinema_siren_forward_node_prep(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
+                                                          ptr(ws.lat), n, npad, ptr(saved), ptr(ws.out), ptr(ng.work), S, lx, ly,
+                                                          lz, self.stream()), "cinema_siren_forward_node_prep")
+            return ws.out
         check(self.lib.cinema_siren_forward(C.byref(self.desc), ptr(self.flat), ptr(self.packed), ptr(ws.coords_t),
                                             ptr(ws.lat), n, npad, ptr(saved), ptr(ws.out), self.stream()),
               "cinema_siren_forward")
@@ -277,14 +286,14 @@ def nodegrad_prepare(eng: "SirenEngine", ng: NodeGrad, coords: torch.Tensor, idx
                      cond_subject: Optional[torch.Tensor], tfs: Optional[torch.Tensor], n: int, rows_ready: bool = False):
     """Interpolation weights of the batch + node rows / centred node projections of the current table (after the packed
     weight copies were refreshed: step_head, or eng.pack(2 | 8)).  rows_ready: step_head(..., ng=ng) of this step wrote
-    the node rows already."""
+    the node rows and the interpolation weights already (only the projections are left)."""
     S, Cc, lx, ly, lz = table.shape
     cond_dims = 0 if cond_subject is None else cond_subject.shape[1]
     npad = round_up(n, ROW_ALIGN)
     ng.ensure(eng, S, npad)
     check(eng.lib.cinema_nodegrad_prepare(C.byref(eng.desc), ptr(eng.packed), ptr(coords), ptr(idx), ptr(tfs),
                                           0 if tfs is None else tfs.shape[1], ptr(table), ptr(cond_subject) if cond_dims else None,
-                                          n, npad, S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), 1 if rows_ready else 0,
+                                          n, npad, S, Cc, lx, ly, lz, cond_dims, ptr(ng.work), 3 if rows_ready else 0,
                                           eng.stream()),
           "cinema_nodegrad_prepare")
 
@@ -424,8 +433,8 @@ def step_head(eng: SirenEngine, st: "TrilerpState", coords: torch.Tensor, idx: t
     """eng.pack() + k1_forward_sorted (+ k1_shadow, + step_prepare) in ONE launch (cinema_step_head); the caller
     checked k1_sorted_eligible and eng.can_skip_saved() (= the activation-stationary bf16 kernels are in use).
     prepare: dict(dcoords, sums, n_cls, class_w, voxel, labels, V, scratch) or None.
-    ng: work buffer of the node-space backward -- its node rows are written in the same launch (nodegrad_prepare is then
-    called with rows_ready=True)."""
+    ng: work buffer of the node-space backward -- its node rows and interpolation weights are written in the same launch
+    (then eng.forward(n, ng=ng, ...) adds the projections, or nodegrad_prepare(..., rows_ready=True) does)."""
     lib, d, ws = eng.lib, eng.desc, eng.ws
     S, Cc, lx, ly, lz = latents.shape
     cond_dims = 0 if cond is None else cond.shape[1]

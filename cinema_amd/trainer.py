@@ -249,9 +249,13 @@ class HotPathTrainer:
             with torch.cuda.stream(self.side):
                 E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n, rows_ready=True)
                 self.ev_prep.record(self.side)
-        elif use_ng:
-            E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n, rows_ready=one_head)   # one launch, in line
-        eng.forward(n)
+        elif use_ng and not one_head:
+            E.nodegrad_prepare(eng, self.ng, coords, subj, table, cond_table, tfs, n)     # one launch (+ the node rows), in line
+        if use_ng and one_head and not ng_on_side:
+            # the head wrote node rows and interpolation weights; the projections ride in the forward launch
+            eng.forward(n, ng=self.ng, latents_shape=tuple(table.shape))
+        else:
+            eng.forward(n)
         if not joined:
             main.wait_event(self.ev_prep)
         E.sample_loss(None, ws.out, n, self.sr_dims, self.n_cls, self.loss_metric, self.class_w, 1.0,

@@ -219,8 +219,9 @@ int cinema_affine_trilerp_fwd_sorted(const float *coords, const int32_t *idx, co
  * after the other on one stream, or with a 6-10 us join on two.  bf16 stacks on the activation-stationary path only
  * (hidden <= 512, `pk_fs >= 0` after planning) and the shapes cinema_affine_trilerp_fwd_sorted takes; LP and the
  * precision come from the descriptor.  Same bits as the separate calls.
- * node_work != NULL (the work buffer of the node-space backward, below): the node rows of the current table are written
- * too, as one more block range -- cinema_nodegrad_prepare is then called with flags & 1 and skips that launch. */
+ * node_work != NULL (the work buffer of the node-space backward, below, sized for this S and Npad; Npad % 128 == 0): the
+ * node rows of the current table and the interpolation weights of the batch are written too, as two more block ranges
+ * -- cinema_nodegrad_prepare is then called with flags 1 | 2 (or not at all, see cinema_siren_forward_node_prep). */
 /* Gradient of the per-subject condition table from the per-sample rows dcond [N x cond_dims] the backward calls leave, for
  * a batch sorted by subject: dtable[s] = sum of the rows with idx == s (what autograd's index_add does for
  * conditions[idcs_df], build_atlas.py:74-75).  One workgroup per subject, ranges by binary search, deterministic. */
@@ -354,7 +355,9 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
  *   cinema_nodegrad_prepare: per step, after the weights were packed (cinema_siren_pack_part with bits 2 | 8, or
  *     cinema_step_head) -- interpolation weights of the batch, node rows and centred node projections of the current
  *     table (`latents` (S, C, lx, ly, lz): the table K1 interpolates; cond_subject [S x cond_dims] or NULL).
- *     flags & 1: cinema_step_head already wrote the node rows of this table into `work` (one launch instead of two).
+ *     flags & 1: cinema_step_head already wrote the node rows of this table into `work` (one launch instead of two);
+ *     flags & 2: ... and the interpolation weights of this batch; flags & 4: the projections are left to
+ *     cinema_siren_forward_node_prep (with 1 | 2 | 4 the call launches nothing).
  *   cinema_siren_backward_nodegrad: flags as cinema_siren_backward (SKIP_WEIGHT_GRADS, GRADS_CLEARED, DCOORDS_CLEARED,
  *     WEIGHTS_FIRST / DLAT_ONLY: the first call leaves grad_params complete, the second one the table-side gradients;
  *     the PHASE bits time single stages on whatever earlier stages left in the buffers: CHAIN = chain kernel +
@@ -362,6 +365,13 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
  *     Outputs (overwritten): grad_params, dlatents (S, C, lx, ly, lz), dembed [S x tf_dim] or NULL, dcond [S x cond_dims]
  *     or NULL (per-SUBJECT condition gradient).  dcoords [Npad x 3] holds the first layer's part only.
  * ------------------------------------------------------------------------------------- */
+/* cinema_siren_forward + the node projections of cinema_nodegrad_prepare in ONE launch: the projections need only the
+ * packed weights and the node rows (both left by cinema_step_head with node_work != NULL), so they run as tail workgroups
+ * of the forward launch, on the CUs its shorter second round of workgroups leaves idle.  A training loop then calls
+ * cinema_step_head(node_work) -> this -> loss -> cinema_siren_backward_nodegrad and never cinema_nodegrad_prepare. */
+int cinema_siren_forward_node_prep(const cinema_siren_desc *d /* host */, const float *params, const void *packed,
+                                   const float *coords_t, const void *lat, int64_t N, int64_t Npad, void *saved, float *out,
+                                   void *node_work, int64_t S, int32_t lx, int32_t ly, int32_t lz, void *stream);
 int cinema_nodegrad_eligible(const cinema_siren_desc *d /* host */, int32_t lx, int32_t ly, int32_t lz);
 int64_t cinema_nodegrad_work_bytes(const cinema_siren_desc *d /* host */, int64_t S, int64_t Npad);
 int cinema_nodegrad_prepare(const cinema_siren_desc *d /* host */, const void *packed, const float *coords, const int32_t *idx,
