@@ -150,28 +150,28 @@ struct StepHeadArgs {
   const float *nm_lat; float *nm_shadow; long nm_S; int nm_C, nm_G;
   StepPrepareArgs pr; NodeRowsCArgs nr; NgWeightArgs ngw;
   int g_k1, g_ps, g_sd, g_job, g_nm, g_pr, g_nr, g_ngw;
+  int skip;      // developer timing (CINEMA_HEAD_SKIP): block ranges switched off, results are wrong then
 };
 __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   int b = blockIdx.x;                            // workgroup-uniform dispatch; the longest dependent-load chains first
-  if (b < a.g_pr) { step_prepare_body(a.pr, b, a.g_pr); return; }
+  if (b < a.g_pr) { if (!(a.skip & 1)) step_prepare_body(a.pr, b, a.g_pr); return; }
   b -= a.g_pr;
-  if (b < a.g_k1) { trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b); return; }
+  if (b < a.g_k1) { if (!(a.skip & 2)) trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b); return; }
   b -= a.g_k1;
   if (b < a.g_ngw) {                             // dependent loads (idx -> embedding row) like K1: early
     __shared__ float ct[16 * NG_WB][4];
-    ng_weights_body<256>(a.ngw, b, ct);
+    if (!(a.skip & 4)) ng_weights_body<256>(a.ngw, b, ct);
     return;
   }
   b -= a.g_ngw;
-  if (b < a.g_job) { pack_job_body<bf16_t>(a.job[b >> 6], a.packed, b & 63, 64); return; }
+  if (b < a.g_job) { if (!(a.skip & 8)) pack_job_body<bf16_t>(a.job[b >> 6], a.packed, b & 63, 64); return; }
   b -= a.g_job;
-  if (b < a.g_ps) { pack_stream_body(a.ps, b, a.g_ps); return; }
+  if (b < a.g_ps) { if (!(a.skip & 16)) pack_stream_body(a.ps, b, a.g_ps); return; }
   b -= a.g_ps;
-  if (b < a.g_sd) { pack_side_body(a.sd, b, a.g_sd); return; }
+  if (b < a.g_sd) { if (!(a.skip & 32)) pack_side_body(a.sd, b, a.g_sd); return; }
   b -= a.g_sd;
-  if (b < a.g_nr) { node_rows_centred_body(a.nr, b); return; }
+  if (b < a.g_nr) { if (!(a.skip & 64)) node_rows_centred_body(a.nr, b); return; }
   b -= a.g_nr;
-
   node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
 }
 
@@ -832,6 +832,9 @@ extern "C" int cinema_step_head(const cinema_siren_desc *d, const float *params,
     a.g_pr = (int)std::max<long>(1, std::min<long>((work + 255) / 256, PREP_MAX_GRID));
     a.pr = StepPrepareArgs{dcoords, (long)n_dcoords, sums, voxel, idx, labels, (long)V, (long)N, n_cls, class_w, scratch};
   }
+  static const int head_skip = getenv("CINEMA_HEAD_SKIP") ? atoi(getenv("CINEMA_HEAD_SKIP")) : 0;
+  a.skip = head_skip;
+  if (head_skip) fprintf(stderr, "[head] grids: prepare %d k1 %d weights %d jobs %d stream %d side %d rows %d shadow %d\n", a.g_pr, a.g_k1, a.g_ngw, a.g_job, a.g_ps, a.g_sd, a.g_nr, a.g_nm);
   hipLaunchKernelGGL(k_step_head, dim3((unsigned)(a.g_k1 + a.g_ps + a.g_sd + a.g_job + a.g_nr + a.g_ngw + a.g_nm + a.g_pr)), dim3(256), 0,
                      (hipStream_t)stream, a);
   CINEMA_CHECK_HIP(hipGetLastError());
