@@ -202,7 +202,17 @@ class INR_Decoder(nn.Module):
     def transform(coords, tfs, inverse=False):
         """c' = A(tfs) c + t per sample (reference: models/inr_decoder.py:64-71) through the K1 kernels."""
         if inverse:
-            raise NotImplementedError("inverse=True is unused by the reference's callers and not built")
+            # c' = R^-1 c - R^-1 t (models/inr_decoder.py:67-69; no caller in the reference): R, t from the K1 kernel, the
+            # 3 x 3 inverses by the adjugate in elementwise device ops.  Forward only -- no gradient reaches tfs / coords.
+            from ..utils import embed2affine
+            R, t = embed2affine(tfs)
+            c = coords.detach().float()
+            a, b, cc, d, e, f, g, h, i = (R[:, r, k] for r in range(3) for k in range(3))
+            A, B, Cf = e * i - f * h, -(d * i - f * g), d * h - e * g
+            inv = torch.stack((torch.stack((A, -(b * i - cc * h), b * f - cc * e), -1),
+                               torch.stack((B, a * i - cc * g, -(a * f - cc * d)), -1),
+                               torch.stack((Cf, -(a * h - b * g), a * e - b * d), -1)), -2) / (a * A + b * B + cc * Cf)[:, None, None]
+            return torch.einsum("nxy,ny->nx", inv, c - t)
         from ..functions_static import TransformFunction
         return TransformFunction.apply(coords, tfs)
 

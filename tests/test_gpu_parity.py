@@ -626,3 +626,22 @@ def test_inference_memory_follows_the_path(monkeypatch):
             small = eng.workspace(128)
             dec.inference(coords, lat, torch.zeros(0, device=dev()), [9, 9, 9], None, step_size=200)
             assert eng.ws is small
+
+
+def test_transform_inverse_undoes_transform():
+    """INR_Decoder.transform(inverse=True) (models/inr_decoder.py:67-69: R^-1, -R^-1 t) against the oracle's affine and as the
+    inverse of the forward transform, for rigid, scaling and shearing embeddings."""
+    from oracle import cinema_oracle as O
+    from cinema_amd.models.inr_decoder import INR_Decoder
+    g = torch.Generator().manual_seed(4)
+    for w in (6, 9, 12):
+        tf = (torch.rand(300, w, generator=g) - 0.5) * 0.4
+        c = torch.rand(300, 3, generator=g) * 2 - 1
+        fwd = INR_Decoder.transform(c.to(dev()), tf.to(dev()))
+        back = INR_Decoder.transform(fwd, tf.to(dev()), inverse=True).cpu()
+        assert float((back - c).abs().max()) < 1e-5
+        R, t = O.affine_from_embedding(tf)
+        Ri = torch.linalg.inv(R)
+        ref = torch.einsum("nxy,ny->nx", Ri, c) - torch.einsum("nij,nj->ni", Ri, t)
+        got = INR_Decoder.transform(c.to(dev()), tf.to(dev()), inverse=True).cpu()
+        assert float((got - ref).abs().max()) < 1e-5
