@@ -1625,7 +1625,7 @@ namespace {
 struct ConvGeom { int S, C, lx, ly, lz, k, G, K3; long R, KK, KKp; };
 
 __device__ __forceinline__ int conv_neighbour(const ConvGeom &g, int n, int tap, int sign) {
-  const int p = g.k >> 1;
+  const int p = (g.k - 1) >> 1;      // padding='same': (k - 1) / 2 in front, the rest behind (torch; equal for odd k)
   const int tz = tap % g.k, ty = (tap / g.k) % g.k, tx = tap / (g.k * g.k);
   const int iz = n % g.lz, iy = (n / g.lz) % g.ly, ix = n / (g.lz * g.ly);
   const int jx = ix + sign * (tx - p), jy = iy + sign * (ty - p), jz = iz + sign * (tz - p);
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_finish(const float *dW2, con
 }
 
 bool conv_geom(int64_t S, int C, int lx, int ly, int lz, int k, ConvGeom &g) {
-  if (S < 1 || C < 8 || C % 8 || C > 4096 || lx < 1 || ly < 1 || lz < 1 || k < 1 || !(k & 1) || k > 15) return false;
+  if (S < 1 || C < 8 || C % 8 || C > 4096 || lx < 1 || ly < 1 || lz < 1 || k < 1 || k > 15) return false;
   if ((long)lx * ly * lz > 4096 || S * lx * ly * lz > (1L << 24)) return false;     // (s, n) rows are int in the GEMM engine
   g.S = (int)S; g.C = C; g.lx = lx; g.ly = ly; g.lz = lz; g.k = k; g.G = lx * ly * lz; g.K3 = k * k * k;
   g.R = ((long)S * g.G + 127) / 128 * 128;
@@ -1794,7 +1794,7 @@ int conv_backward_impl(const ConvGeom &g, const ConvWork &w, const float *in, co
 extern "C" int64_t cinema_conv_mod_work_bytes(int64_t S, int32_t C, int32_t lx, int32_t ly, int32_t lz, int32_t k, int32_t precision) {
   ConvGeom g;
   if (!conv_geom(S, C, lx, ly, lz, k, g) || (precision != CINEMA_PREC_F32 && precision != CINEMA_PREC_BF16)) {
-    cinema_set_error("cinema_conv_mod_work_bytes: need S >= 1, C a multiple of 8 (<= 4096), an odd kernel size <= 15, at most 4096 nodes per subject and 2^24 in all, a valid precision");
+    cinema_set_error("cinema_conv_mod_work_bytes: need S >= 1, C a multiple of 8 (<= 4096), a kernel size <= 15, at most 4096 nodes per subject and 2^24 in all, a valid precision");
     return -1;
   }
   return (int64_t)conv_work(g, precision).bytes;

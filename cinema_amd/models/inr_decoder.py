@@ -33,8 +33,6 @@ class Modulator(nn.Module):
         self.kernel_size = kernel_size
         self.precision = precision
         if kernel_size > 0:
-            if kernel_size % 2 == 0:
-                raise NotImplementedError("cinema_amd Modulator: even cnn_kernel_size (asymmetric 'same' padding) is not built")
             self.conv = nn.Conv3d(latent_dims[0], latent_dims[0], kernel_size, padding="same")
         else:
             self.conv = nn.Identity()

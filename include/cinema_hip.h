@@ -156,7 +156,7 @@ int cinema_sine_layer_backward(const cinema_sine_layer_desc *d, const float *W, 
 
 /* Modulator with cnn_kernel_size = k > 0 -- Conv3d(C, C, k, padding='same') over the latent table, models/inr_decoder.py:
  * 109-123 (the default k = 0 is the identity and needs no call).  in / out / dout / din [S x C x lx x ly x lz] fp32,
- * W [C x C x k x k x k], b [C] (torch layouts).  k odd, C a multiple of 8.  The convolution runs as GEMMs over an im2col
+ * W [C x C x k x k x k], b [C] (torch layouts).  k <= 15 (even k: (k - 1) / 2 zeros in front, the rest behind, as torch pads), C a multiple of 8.  The convolution runs as GEMMs over an im2col
  * image of the table (three for the backward), in the arithmetic `precision` selects.  work: cinema_conv_mod_work_bytes
  * bytes of device memory; the two calls are independent (the backward rebuilds what it needs from `in`).
  * The backward overwrites din, dW, db (what autograd leaves for the table, conv.weight and conv.bias). */

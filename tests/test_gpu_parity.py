@@ -537,11 +537,13 @@ def test_inference_forward_keeps_nothing_and_matches():
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("S,C,grid,k", [(5, 48, (3, 3, 3), 3), (64, 256, (3, 3, 3), 3), (3, 16, (2, 3, 4), 5), (2, 32, (1, 1, 1), 3)])
+@pytest.mark.parametrize("S,C,grid,k", [(5, 48, (3, 3, 3), 3), (64, 256, (3, 3, 3), 3), (3, 16, (2, 3, 4), 5), (2, 32, (1, 1, 1), 3),
+                                       (4, 24, (3, 3, 3), 2), (3, 16, (3, 4, 2), 4)])
 def test_conv_modulator_matches_torch_conv3d(S, C, grid, k, precision):
     """Modulator with cnn_kernel_size > 0 (models/inr_decoder.py:109-123): forward and all three
     gradients of Conv3d(C, C, k, padding='same') over the latent table against torch's conv3d in float64 on the host
-    (the reference's own op), incl. the bench's table size, a non-cubic grid with a kernel wider than the grid, 1^3."""
+    (the reference's own op), incl. the bench's table size, a non-cubic grid with a kernel wider than the grid, 1^3, and even
+    kernel sizes (torch pads (k - 1) / 2 in front and the rest behind)."""
     import torch.nn.functional as F
     from cinema_amd.models.inr_decoder import Modulator
     torch.manual_seed(S * 1000 + C)
