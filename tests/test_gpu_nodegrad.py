@@ -95,3 +95,34 @@ def test_two_call_backward_of_a_rank_of_several_equals_the_single_call(node_grad
         errs.update(both_errs("g_" + k, got_v[k].cpu().numpy(), ref_v[k].cpu().numpy()))
     bad = failing(errs, 1e-5, 1e-5)        # the same kernels on the same operands; float atomics in the bias sums
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cond_dims", [0, 1])
+def test_node_tables_riding_in_head_and_forward_equal_the_stand_alone_preparation(cond_dims):
+    """cinema_step_head(node_work) + cinema_siren_forward_train(node_work) leave the same bits in the work buffer as
+    cinema_nodegrad_prepare on its own (node rows, centred rows, interpolation weights, axes, subject offsets, projections),
+    and the forward's outputs are those of cinema_siren_forward."""
+    from cinema_amd import engine as E
+    S, C, n, hidden = 7, 60, 1500, 256          # lat = 60 (+ 1 condition): LP = 64 with zero padding
+    d = E.make_desc(3, C + cond_dims, 12, hidden, 4, [1, 3], 30, 30, E._lib.PREC_BF16)
+    eng = E.SirenEngine(d, torch.device(DEV))
+    g = torch.Generator().manual_seed(3)
+    eng.flat.copy_((torch.randn(eng.flat.shape, generator=g) * 0.05).to(DEV))
+    latents = (torch.randn(S, C, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    cond = (torch.randn(S, cond_dims, generator=g) * 0.1).to(DEV) if cond_dims else None
+    tfs = ((torch.rand(S, 9, generator=g) - 0.5) * 0.1).to(DEV)
+    coords = (torch.rand(n, 3, generator=g) * 2.2 - 1.1).to(DEV)          # some samples outside the grid (clamped axes)
+    idx = torch.randint(0, S, (n,), generator=g, dtype=torch.int32).sort().values.to(DEV)
+    assert E.nodegrad_eligible(eng, tuple(latents.shape))
+    eng.workspace(n)
+    st = E.TrilerpState()
+    a, b = E.NodeGrad(), E.NodeGrad()
+    E.step_head(eng, st, coords, idx, latents, cond, tfs, n, shadow=False, cond_by_subject=True, ng=a)
+    out_a = eng.forward(n, ng=a, latents_shape=tuple(latents.shape)).clone()
+    saved_a = eng.ws.saved.clone()
+    E.nodegrad_prepare(eng, b, coords, idx, latents, cond, tfs, n)          # rows + weights + projections, two launches
+    out_b = eng.forward(n).clone()
+    torch.cuda.synchronize()
+    assert a.work is not b.work and torch.equal(a.work, b.work)
+    assert torch.equal(out_a, out_b) and torch.equal(saved_a, eng.ws.saved)
+    assert int(a.work.count_nonzero()) > 0
