@@ -153,14 +153,18 @@ struct StepHeadArgs {
   int skip;      // developer timing (CINEMA_HEAD_SKIP): block ranges switched off, results are wrong then
 };
 __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
+  // ONE LDS pool for whichever body this workgroup runs (the K1 forward's 32 000 B decide): as static arrays of the bodies
+  // they added up to 41.5 KB = three workgroups per CU for 4 100 workgroups; now five
+  __shared__ __attribute__((aligned(16))) char pool[TFS_LDS_BYTES(27)];
+  static_assert(TFS_LDS_BYTES(27) >= NODE_MAJOR_LDS_BYTES && TFS_LDS_BYTES(27) >= NODE_ROWS_LDS_BYTES &&
+                TFS_LDS_BYTES(27) >= 16 * NG_WB * 16 && TFS_LDS_BYTES(27) >= STEP_PREPARE_LDS_BYTES, "head LDS pool");
   int b = blockIdx.x;                            // workgroup-uniform dispatch; the longest dependent-load chains first
-  if (b < a.g_pr) { if (!(a.skip & 1)) step_prepare_body(a.pr, b, a.g_pr); return; }
+  if (b < a.g_pr) { if (!(a.skip & 1)) step_prepare_body(a.pr, b, a.g_pr, pool); return; }
   b -= a.g_pr;
-  if (b < a.g_k1) { if (!(a.skip & 2)) trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b); return; }
+  if (b < a.g_k1) { if (!(a.skip & 2)) trilerp_fwd_sorted_body<bf16_t, 3, 3, 3>(a.k1, b, pool); return; }
   b -= a.g_k1;
   if (b < a.g_ngw) {                             // dependent loads (idx -> embedding row) like K1: early
-    __shared__ float ct[16 * NG_WB][4];
-    if (!(a.skip & 4)) ng_weights_body<256>(a.ngw, b, ct);
+    if (!(a.skip & 4)) ng_weights_body<256>(a.ngw, b, reinterpret_cast<float (*)[4]>(pool));
     return;
   }
   b -= a.g_ngw;
@@ -170,9 +174,9 @@ __global__ __launch_bounds__(256) void k_step_head(StepHeadArgs a) {
   b -= a.g_ps;
   if (b < a.g_sd) { if (!(a.skip & 32)) pack_side_body(a.sd, b, a.g_sd); return; }
   b -= a.g_sd;
-  if (b < a.g_nr) { if (!(a.skip & 64)) node_rows_centred_body(a.nr, b); return; }
+  if (b < a.g_nr) { if (!(a.skip & 64)) node_rows_centred_body(a.nr, b, pool); return; }
   b -= a.g_nr;
-  node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b);
+  node_major_body(a.nm_lat, a.nm_S, a.nm_C, a.nm_G, a.nm_shadow, b, pool);
 }
 
 #include "fused_dev.h"

@@ -202,13 +202,16 @@ struct TriFwdSortedArgs {
 #define TFS_THREADS 256
 #define TFS_CMAX 256
 
+// LDS of the body (the caller's __shared__ pool, 16-byte aligned): inside k_step_head every block range carves its arrays
+// from ONE pool -- as static arrays of each body they add up, and the sum decides how many workgroups a CU holds
+#define TFS_LDS_BYTES(G) ((G) * TFS_CMAX * 4 + TFS_CHUNK * 8 * 4 * 2 + TFS_CHUNK * 4)
 template <typename T, int LX, int LY, int LZ>
-__device__ __forceinline__ void trilerp_fwd_sorted_body(const TriFwdSortedArgs &a, const int vbid) {
+__device__ __forceinline__ void trilerp_fwd_sorted_body(const TriFwdSortedArgs &a, const int vbid, char *pool) {
   constexpr int G = LX * LY * LZ;
-  __shared__ __attribute__((aligned(16))) float tab[G * TFS_CMAX];    // [node][channel]
-  __shared__ __attribute__((aligned(16))) float cw[TFS_CHUNK * 8];    // corner weights
-  __shared__ __attribute__((aligned(16))) int cn[TFS_CHUNK * 8];      // corner nodes
-  __shared__ int sid[TFS_CHUNK];
+  float *tab = reinterpret_cast<float *>(pool);           // [node][channel]
+  float *cw = tab + G * TFS_CMAX;                         // corner weights [TFS_CHUNK * 8]
+  int *cn = reinterpret_cast<int *>(cw + TFS_CHUNK * 8);  // corner nodes [TFS_CHUNK * 8]
+  int *sid = cn + TFS_CHUNK * 8;                          // [TFS_CHUNK]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long base = (long)vbid * TFS_CHUNK;
@@ -314,6 +317,7 @@ __device__ __forceinline__ void trilerp_fwd_sorted_body(const TriFwdSortedArgs &
 
 template <typename T, int LX, int LY, int LZ>
 __global__ __launch_bounds__(TFS_THREADS) void k_trilerp_fwd_sorted(TriFwdSortedArgs a) {
-  trilerp_fwd_sorted_body<T, LX, LY, LZ>(a, (int)blockIdx.x);
+  __shared__ __attribute__((aligned(16))) char pool[TFS_LDS_BYTES(LX * LY * LZ)];
+  trilerp_fwd_sorted_body<T, LX, LY, LZ>(a, (int)blockIdx.x, pool);
 }
 

@@ -21,7 +21,10 @@ __global__ void k_class_weight_sum(const float *target, int tcols, const int64_t
   if ((threadIdx.x & 63) == 0) atomicAdd(sums + 2, acc);
 }
 
-__global__ __launch_bounds__(256) void k_step_prepare(StepPrepareArgs a) { step_prepare_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_step_prepare(StepPrepareArgs a) {
+  __shared__ __attribute__((aligned(16))) char pool[STEP_PREPARE_LDS_BYTES];
+  step_prepare_body(a, blockIdx.x, gridDim.x, pool);
+}
 
 struct LossArgs {
   const float *out; const float *target; const int64_t *voxel; const int32_t *subj; const float *intens;

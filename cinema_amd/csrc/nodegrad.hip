@@ -16,7 +16,10 @@ namespace {
 #include "dw_device.h"
 
 // everything the node-space backward needs before it can start (behind the node rows), in ONE launch (block ranges)
-__global__ __launch_bounds__(256) void k_ng_rows(NodeRowsCArgs a) { node_rows_centred_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_ng_rows(NodeRowsCArgs a) {
+  __shared__ __attribute__((aligned(16))) char pool[NODE_ROWS_LDS_BYTES];
+  node_rows_centred_body(a, blockIdx.x, pool);
+}
 struct NgPrepArgs { NgWeightArgs w; NgProjArgs p; int g_w; };
 __global__ __launch_bounds__(512) void k_ng_prepare(NgPrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

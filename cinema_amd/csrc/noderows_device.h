@@ -10,9 +10,10 @@
 #pragma once
 
 struct NodeRowsCArgs { const float *latents; const float *cond; long S; int C, G, cond_dims, LP; bf16_t *T, *Tc; };
-__device__ __forceinline__ void node_rows_centred_body(const NodeRowsCArgs &a, unsigned vbid) {
-  __shared__ float stage[32 * 32];          // [column][G], G <= 31
-  __shared__ float mean[32];
+#define NODE_ROWS_LDS_BYTES ((32 * 32 + 32) * 4)
+__device__ __forceinline__ void node_rows_centred_body(const NodeRowsCArgs &a, unsigned vbid, char *pool) {
+  float *stage = reinterpret_cast<float *>(pool);   // [column][G], G <= 31  (the caller's __shared__ pool)
+  float *mean = stage + 32 * 32;                    // [32]
   const int nchunk = a.LP >> 5, tid = threadIdx.x;
   const long s = vbid / nchunk;
   const int c0 = (int)(vbid % nchunk) * 32;

@@ -11,8 +11,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // latent table (S, C, G) -> node-major shadow (S, G, C): one workgroup per (subject, 32 x 32 tile) through LDS;
 // vbid = tile_g + tiles_g * (tile_c + tiles_c * subject)
-__device__ __forceinline__ void node_major_body(const float *lat, long S, int C, int G, float *shadow, unsigned vbid) {
-  __shared__ float tile[32][33];
+#define NODE_MAJOR_LDS_BYTES (32 * 33 * 4)
+__device__ __forceinline__ void node_major_body(const float *lat, long S, int C, int G, float *shadow, unsigned vbid, char *pool) {
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(pool);      // [32][33] in the caller's __shared__ pool
   const unsigned tg = (G + 31) / 32, tc = (C + 31) / 32;
   const long s = vbid / (tg * tc);
   const int c0 = (int)((vbid / tg) % tc) * 32, g0 = (int)(vbid % tg) * 32;
@@ -38,9 +39,10 @@ struct StepPrepareArgs {
   float *dcoords; long n_dcoords; float *sums; const int64_t *voxel; const int32_t *subj; const uint8_t *labels; long V, N;
   int n_cls; const float *class_w; float *scratch;
 };
-__device__ __forceinline__ void step_prepare_body(const StepPrepareArgs &a, unsigned vbid, unsigned vgrid) {
-  __shared__ float red[4];
-  __shared__ int last;
+#define STEP_PREPARE_LDS_BYTES 32
+__device__ __forceinline__ void step_prepare_body(const StepPrepareArgs &a, unsigned vbid, unsigned vgrid, char *pool) {
+  float *red = reinterpret_cast<float *>(pool);                   // [4] + one flag, in the caller's __shared__ pool
+  int &last = *reinterpret_cast<int *>(pool + 16);
   const int tid = threadIdx.x;
   float acc = 0.f;
   if (a.class_w != nullptr) {

@@ -53,7 +53,8 @@ __global__ void k_affine_bwd(const float *coords, const int32_t *idx, const floa
 }
 
 __global__ __launch_bounds__(256) void k_node_major(const float *lat, long S, int C, int G, float *shadow) {
-  node_major_body(lat, S, C, G, shadow, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) char pool[NODE_MAJOR_LDS_BYTES];
+  node_major_body(lat, S, C, G, shadow, blockIdx.x, pool);
 }
 
 
