@@ -126,3 +126,53 @@ def test_node_tables_riding_in_head_and_forward_equal_the_stand_alone_preparatio
     assert a.work is not b.work and torch.equal(a.work, b.work)
     assert torch.equal(out_a, out_b) and torch.equal(saved_a, eng.ws.saved)
     assert int(a.work.count_nonzero()) > 0
+
+
+@pytest.mark.parametrize("case", ["one_subject_few_rows", "grid_1x1x1", "grid_2x3x4", "no_tf", "single_rows"])
+def test_node_gradients_odd_shapes(case, monkeypatch):
+    """Corners of the node-space backward against the per-sample one: a single subject with fewer rows than one tile, a
+    1-node and a non-cubic 24-node grid (the batch then goes through the generic K1 forward and the stand-alone
+    preparation), no transformation table (tf_dim = 0), subjects with a single sample each."""
+    from cinema_amd.trainer import SubjectStore
+    S, side, latent_dim, hidden, layers, mod, n, tf_dim = 4, 16, [32, 3, 3, 3], 128, 2, [0, 2], 333, 6
+    if case == "one_subject_few_rows":
+        S, n = 1, 5
+    elif case == "grid_1x1x1":
+        latent_dim = [32, 1, 1, 1]
+    elif case == "grid_2x3x4":
+        latent_dim = [32, 2, 3, 4]
+    elif case == "no_tf":
+        tf_dim = 0
+    args = base_args(latent_dim, hidden, layers, mod, [2, 10], 0, "bf16", tf_dim=tf_dim)
+    store = SubjectStore.synthetic(S, (side, side, side), 155.0 / side, [155, 155, 155], 2, 10, seed=13, device=DEV)
+    if case == "single_rows":       # one sample per subject
+        first = torch.zeros(len(store), dtype=torch.bool, device=DEV)
+        for s in range(S):
+            first[int((store.subj == s).nonzero()[0])] = True
+        store.coords, store.voxel, store.subj = store.coords[first], store.voxel[first], store.subj[first]
+        n = S
+    store.shuffle(torch.Generator(device=DEV).manual_seed(1), group_chunk=n)
+
+    def one(node_grad):
+        from cinema_amd.trainer import HotPathTrainer
+        monkeypatch.setenv("CINEMA_NODE_GRAD", "1" if node_grad else "0")
+        torch.manual_seed(21)
+        tr = HotPathTrainer(args, store, DEV, keep_grads=True)
+        with torch.no_grad():
+            if tf_dim:
+                tr.tfs.copy_((torch.rand(tr.tfs.shape, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.05)
+            for k, v in tr.eng.param_views().items():
+                if "linear_lats.weight" in k:
+                    v.mul_(3.0)
+        tr.step(0, n)
+        torch.cuda.synchronize()
+        return tr.lat_grad.clone(), tr.tf_grad.clone(), tr.eng.param_views(tr.eng.flat_grad.clone())
+
+    ref, got = one(False), one(True)
+    errs = both_errs("glat", got[0].cpu().numpy(), ref[0].cpu().numpy())
+    if tf_dim:
+        errs.update(both_errs("gtf", got[1].cpu().numpy(), ref[1].cpu().numpy()))
+    for k in ref[2]:
+        errs.update(both_errs("g_" + k, got[2][k].cpu().numpy(), ref[2][k].cpu().numpy()))
+    bad = failing(errs, 1e-2, 6e-3)
+    assert not bad, bad
