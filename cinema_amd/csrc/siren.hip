@@ -1634,18 +1634,54 @@ __device__ __forceinline__ int conv_neighbour(const ConvGeom &g, int n, int tap,
 }
 
 // TRANSPOSED = false: col [R][KKp] (channel fastest); true: colT [KKp][R] ((s, n) fastest).  Pads are written as zeros.
+// A thread makes eight consecutive destination elements (C % 8 == 0, R % 128 == 0): all eight gathers are requested before
+// the first conversion, one 16-byte (bf16) or two (fp32) stores -- one 2-byte store per thread took 62 us per call at the
+// cfg-D table.  `zero` (n_zero floats): the split-K GEMM that follows accumulates with atomics; its output is cleared here
+// instead of by a fill launch of its own.
 template <typename T, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void k_conv_im2col(const float *x, ConvGeom g, int sign, T *dst) {
-  const long total = g.R * g.KKp;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long row = TRANSPOSED ? e % g.R : e / g.KKp, kc = TRANSPOSED ? e / g.R : e % g.KKp;
-    float v = 0.f;
-    if (row < (long)g.S * g.G && kc < g.KK) {
-      const int s = (int)(row / g.G), n = (int)(row % g.G), tap = (int)(kc / g.C), c = (int)(kc % g.C);
-      const int nb = conv_neighbour(g, n, tap, sign);
-      if (nb >= 0) v = x[((long)s * g.C + c) * g.G + nb];
+__global__ __launch_bounds__(256) void k_conv_im2col(const float *x, ConvGeom g, int sign, T *dst, float *zero, long n_zero) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_zero / 4; e += (long)gridDim.x * 256) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(zero + 4 * e) = z;
+  }
+  const long total8 = g.R * g.KKp / 8;
+  const long SG = (long)g.S * g.G;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total8; q += (long)gridDim.x * 256) {
+    float v[8];
+    bool ok[8];
+    if (TRANSPOSED) {
+      const long kc = q / (g.R / 8), row0 = (q - kc * (g.R / 8)) * 8;       // eight consecutive (s, n) rows of one (tap, c)
+      const int tap = (int)(kc / g.C), c = (int)(kc % g.C);
+      // the tap's offset and the first row's node coordinates once, then a carry chain (ten integer divisions per element
+      // made this variant VALU-bound: 55 us)
+      const int p = (g.k - 1) >> 1;
+      const int oz = sign * (tap % g.k - p), oy = sign * ((tap / g.k) % g.k - p), ox = sign * (tap / (g.k * g.k) - p);
+      int s = (int)(row0 / g.G), n = (int)(row0 % g.G);
+      int iz = n % g.lz, iy = (n / g.lz) % g.ly, ix = n / (g.lz * g.ly);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int jx = ix + ox, jy = iy + oy, jz = iz + oz;
+        ok[j] = row0 + j < SG && kc < g.KK && jx >= 0 && jx < g.lx && jy >= 0 && jy < g.ly && jz >= 0 && jz < g.lz;
+        const int nb = (jx * g.ly + jy) * g.lz + jz;
+        v[j] = x[((long)(ok[j] ? s : 0) * g.C + (ok[j] ? c : 0)) * g.G + (ok[j] ? nb : 0)];
+        if (++iz == g.lz) { iz = 0; if (++iy == g.ly) { iy = 0; if (++ix == g.lx) { ix = 0; ++s; } } }
+      }
+    } else {
+      const long row = q / (g.KKp / 8), kc0 = (q - row * (g.KKp / 8)) * 8;    // eight consecutive channels of one (row, tap)
+      const int s = (int)(row / g.G), n = (int)(row % g.G), tap = (int)(kc0 / g.C), c0 = (int)(kc0 % g.C);
+      const int nb = (row < SG && kc0 < g.KK) ? conv_neighbour(g, n, tap, sign) : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ok[j] = nb >= 0;
+        v[j] = x[((long)(ok[j] ? s : 0) * g.C + (ok[j] ? c0 + j : 0)) * g.G + (ok[j] ? nb : 0)];
+      }
     }
-    dst[e] = (T)v;
+    T o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (T)(ok[j] ? v[j] : 0.f);
+    T *out = dst + q * 8;
+    *reinterpret_cast<u32x4 *>(out) = *reinterpret_cast<const u32x4 *>(o);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<u32x4 *>(out + 4) = *reinterpret_cast<const u32x4 *>(o + 4);
   }
 }
 
@@ -1734,8 +1770,9 @@ ConvWork conv_work(const ConvGeom &g, int precision) {
 
 // out[M x K] (zeroed here) = sum over `nrows` rows of P[n][0..M) * Q[n][0..K): one k_dw_grouped problem, split over rows
 template <typename T>
-int conv_gemm(const void *P, int ldp, const void *Q, int ldq, float *out, int ldo, int M, int K, long nrows, hipStream_t s) {
-  CINEMA_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * ldo * sizeof(float), s));
+int conv_gemm(const void *P, int ldp, const void *Q, int ldq, float *out, int ldo, int M, int K, long nrows, hipStream_t s,
+              bool out_cleared = false) {
+  if (!out_cleared) CINEMA_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * ldo * sizeof(float), s));
   DwArgs w = {};
   DwProb pr = {P, Q, out, ldp, ldq, ldo, M, K, (K + 127) / 128};
   w.p[0] = pr;
@@ -1758,10 +1795,10 @@ int conv_forward_impl(const ConvGeom &g, const ConvWork &w, const float *in, con
   char *wk = (char *)work;
   T *colT = (T *)(wk + w.colT), *wT = (T *)(wk + w.wT);
   float *outT = (float *)(wk + w.outT);
-  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, in, g, 1, colT);
+  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp / 8)), dim3(256), 0, s, in, g, 1, colT, outT, (long)g.C * g.R);
   hipLaunchKernelGGL((k_conv_pack_w<T>), dim3(conv_grid(g.KKp * g.C)), dim3(256), 0, s, W, g, 0, wT);
   CINEMA_CHECK_HIP(hipGetLastError());
-  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s)) return rc;
+  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s, true)) return rc;
   hipLaunchKernelGGL(k_conv_untranspose, dim3(conv_grid((long)g.S * g.C * g.G)), dim3(256), 0, s, outT, b, g, out);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1774,17 +1811,17 @@ int conv_backward_impl(const ConvGeom &g, const ConvWork &w, const float *in, co
   T *colT = (T *)(wk + w.colT), *col = (T *)(wk + w.col), *wT = (T *)(wk + w.wT), *rows = (T *)(wk + w.rows);
   float *outT = (float *)(wk + w.outT), *dW2 = (float *)(wk + w.dW2);
   // d weight (+ d bias)
-  hipLaunchKernelGGL((k_conv_im2col<T, false>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, in, g, 1, col);
+  hipLaunchKernelGGL((k_conv_im2col<T, false>), dim3(conv_grid(g.R * g.KKp / 8)), dim3(256), 0, s, in, g, 1, col, dW2, (long)g.C * g.KKp);
   hipLaunchKernelGGL((k_conv_rows<T>), dim3(conv_grid(g.R * g.C)), dim3(256), 0, s, dout, g, rows);
   CINEMA_CHECK_HIP(hipGetLastError());
-  if (int rc = conv_gemm<T>(rows, g.C, col, (int)g.KKp, dW2, (int)g.KKp, g.C, (int)g.KK, g.R, s)) return rc;
+  if (int rc = conv_gemm<T>(rows, g.C, col, (int)g.KKp, dW2, (int)g.KKp, g.C, (int)g.KK, g.R, s, true)) return rc;
   hipLaunchKernelGGL(k_conv_wgrad_finish, dim3(g.C), dim3(256), 0, s, dW2, dout, g, dW, db);
   CINEMA_CHECK_HIP(hipGetLastError());
   // d input: the same GEMM shape as the forward on the mirrored image of dout
-  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp)), dim3(256), 0, s, dout, g, -1, colT);
+  hipLaunchKernelGGL((k_conv_im2col<T, true>), dim3(conv_grid(g.R * g.KKp / 8)), dim3(256), 0, s, dout, g, -1, colT, outT, (long)g.C * g.R);
   hipLaunchKernelGGL((k_conv_pack_w<T>), dim3(conv_grid(g.KKp * g.C)), dim3(256), 0, s, W, g, 1, wT);
   CINEMA_CHECK_HIP(hipGetLastError());
-  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s)) return rc;
+  if (int rc = conv_gemm<T>(wT, g.C, colT, (int)g.R, outT, (int)g.R, g.C, g.S * g.G, g.KKp, s, true)) return rc;
   hipLaunchKernelGGL(k_conv_untranspose, dim3(conv_grid((long)g.S * g.C * g.G)), dim3(256), 0, s, outT, (const float *)nullptr, g, din);
   CINEMA_CHECK_HIP(hipGetLastError());
   return 0;
