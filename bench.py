@@ -429,6 +429,8 @@ def main():
     ap.add_argument("--subjects", type=int, default=64, help="subjects per GPU")
     ap.add_argument("--grid", type=int, default=310, help="voxels per axis of each synthetic subject")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--hidden", type=int, default=512, help="hidden width (the headline metric is quoted at 512; 1024 = the "
+                    "reference's config default, layer-by-layer kernels: use with --profile-step, the roofline objects assume 512)")
     ap.add_argument("--loss", default="mse", choices=["mse", "l1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-atlas", action="store_true", help="train mode: leave out the \"atlas\" object (one 310^3 volume, ~1 s)")
@@ -485,7 +487,7 @@ def main():
         return run_atlas(opt, dev)
 
     from cinema_amd.trainer import HotPathTrainer, SubjectStore
-    args = make_args(512, opt.precision, opt.loss, opt.n_samples)
+    args = make_args(opt.hidden, opt.precision, opt.loss, opt.n_samples)
     torch.manual_seed(42)           # identical MLP init on every rank (replicated weights)
     spacing = 155.0 / opt.grid
     t0 = time.time()
@@ -539,10 +541,10 @@ def main():
     value = world * opt.steps * n / elapsed
     step_tflops = value * tot_f / 1e12
     res = {
-        "metric": "coord samples/sec fwd+bwd (hidden 512)", "value": value, "unit": "coord samples/s", "n_gpus": world,
+        "metric": f"coord samples/sec fwd+bwd (hidden {opt.hidden})", "value": value, "unit": "coord samples/s", "n_gpus": world,
         "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": elapsed / opt.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": opt.precision, "data": "synthetic" if not opt.rehearse_on_one_gpu else "synthetic (REHEARSAL on one GPU over gloo: not a result)",
-        "config": {"workload": "dhcp_neo_mm shape on MI355X: latent 256x3x3x3, hidden 512, 5 hidden layers (mod 1,3,5), "
+        "config": {"workload": f"dhcp_neo_mm shape on MI355X: latent 256x3x3x3, hidden {opt.hidden}, 5 hidden layers (mod 1,3,5), "
                                f"out 2+10, {opt.subjects} synthetic subjects of {opt.grid}^3 voxels per GPU, "
                                f"n_samples {n} per GPU per step, {opt.loss} + weighted CE, AdamW step included",
                    "global_batch": world * n, "parallelism": f"dp{world} (subjects sharded, MLP grads all-reduced)"},
