@@ -88,8 +88,9 @@ def test_work_size_queries_validate_their_arguments():
     from cinema_amd import _lib
     lib = _lib.load()
     assert lib.cinema_conv_mod_work_bytes(64, 256, 3, 3, 3, 3, _lib.PREC_BF16) > 0
+    assert lib.cinema_conv_mod_work_bytes(64, 256, 3, 3, 3, 2, _lib.PREC_BF16) > 0          # even kernel sizes are built (round 3)
     for bad in [(0, 256, 3, 3, 3, 3, _lib.PREC_BF16), (64, 250, 3, 3, 3, 3, _lib.PREC_BF16),      # S, C % 8
-                (64, 256, 3, 3, 3, 2, _lib.PREC_BF16), (64, 256, 3, 3, 3, 3, 7),                   # even kernel, precision
+                (64, 256, 3, 3, 3, 17, _lib.PREC_BF16), (64, 256, 3, 3, 3, 3, 7),                  # kernel > 15, precision
                 (64, 256, 17, 17, 17, 3, _lib.PREC_F32), (1 << 22, 256, 3, 3, 3, 3, _lib.PREC_F32)]:   # too many nodes
         assert lib.cinema_conv_mod_work_bytes(*bad) == -1
         assert b"cinema_conv_mod_work_bytes" in lib.cinema_last_error()
