@@ -22,8 +22,16 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
 // node_work != NULL: the node projections of the node-space backward (nodegrad.h) ride as tail workgroups of the launch
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
-                         hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr, bool lat_bias = true);
+                         hipStream_t s, void *dout16 = nullptr, float *dbf = nullptr, bool lat_bias = true,
+                         float *colsum_rep = nullptr, int rep_w = 0);
+// colsum_rep != NULL (wide kernel only): the b_l and first-layer weight gradient sums go into the replicas of nodegrad.h
 // lat_bias = false: the linear_lats bias gradients are left to the caller (node gradients take them from dU)
+// fused_wide.hip: the same backward chain for workgroups of up to 112 samples (two accumulator passes per wave); it reads
+// the backward stream in the pair-major feature map, so packing and launch both ask fused_bwd_wide(d)
+bool fused_bwd_wide(const cinema_siren_desc *d);
+int wide_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
+                        const float *dout, int64_t Npad, void *gbuf, float *grad_params, float *dcoords, bool wgrads,
+                        hipStream_t s, void *dout16, float *dbf, bool lat_bias, float *colsum_rep, int rep_w);
 
 // "nodes" path (fused_nodes.hip, node.hip; layout in nodes.h): the same chain kernels with the FiLM modulation read from
 // per-subject node tables.  Its forward stream (pk_ns) holds the main weights only.

@@ -58,7 +58,8 @@ void plan_bwd_stream(const cinema_siren_desc *d, StreamPlan &p) {
 
 // two streams (forward, backward chain) packed by one launch: segments [0, nseg0) belong to stream 0
 struct PackStreamArgs { Seg seg[FUSED_MAX_SEGS]; int nseg0, nseg1, steps0, steps1, nslab; const float *params; bf16_t *dst0, *dst1;
-                        int pairmap; };  // 1: fused_nodes.hip's feature map (a lane's fragments 2p, 2p+1 hold 8 consecutive features)
+                        int pairmap; };  // bit 0 / bit 1: stream 0 / 1 in the pair-major feature map of fused_nodes.hip; bit 2: stream 1 in fused_wide.hip's map
+                                         // (a lane's fragments 2p, 2p+1 hold 8 consecutive features)
 
 // (vbid, vgrid): the workgroup's index and count among the workgroups doing this job -- the kernels below run either
 // as launches of their own or as block ranges of k_step_head
@@ -76,7 +77,8 @@ __device__ __forceinline__ void pack_stream_body(const PackStreamArgs &a, unsign
     while (si + 1 < send && step >= a.seg[si + 1].step0) ++si;
     const Seg sg = a.seg[si];
     const int kk = step - sg.step0, i = lane & 15, gk = lane >> 4;
-    const int feat = a.pairmap ? slab * 64 + 32 * (ft >> 1) + 8 * (i >> 2) + 4 * (ft & 1) + (i & 3)
+    const int feat = (second && (a.pairmap & 4)) ? 128 * (slab >> 1) + 64 * (ft >> 1) + 32 * (slab & 1) + 8 * (i >> 2) + 4 * (ft & 1) + (i & 3)
+                     : ((a.pairmap >> (second ? 1 : 0)) & 1) ? slab * 64 + 32 * (ft >> 1) + 8 * (i >> 2) + 4 * (ft & 1) + (i & 3)
                                : slab * 64 + 16 * (i >> 2) + 4 * ft + (i & 3);
     const int k0 = 32 * kk + 8 * gk;
     const float *src = a.params + sg.src;
@@ -737,7 +739,7 @@ static int fused_pack_args(const cinema_siren_desc *d, const float *params, void
   for (int k = 0; k < p0.nseg; ++k) a.seg[k] = p0.seg[k];
   for (int k = 0; k < p1.nseg; ++k) a.seg[p0.nseg + k] = p1.seg[k];
   a.nseg0 = p0.nseg; a.nseg1 = p1.nseg; a.steps0 = p0.steps; a.steps1 = p1.steps; a.nslab = d->HP / 64;
-  a.params = params; a.pairmap = nodes ? 1 : 0;
+  a.params = params; a.pairmap = nodes ? 3 : (fused_bwd_wide(d) ? 4 : 0);
   a.dst0 = (bf16_t *)packed + (nodes ? d->pk_ns : d->pk_fs); a.dst1 = (bf16_t *)packed + (nodes ? d->pk_nb : d->pk_bs);
   const long nchunk = (long)a.nslab * (a.steps0 + a.steps1) * 256;
   CINEMA_REQUIRE(nchunk < (1L << 31), "fused_pack: weight streams too large for 32-bit chunk indices");
@@ -938,8 +940,10 @@ int fused_forward(const cinema_siren_desc *d, const float *params, const void *p
 
 int fused_backward_chain(const cinema_siren_desc *d, const void *packed, const float *coords_t, const void *saved,
                          const float *dout, int64_t Npad, void *gbuf, float *gp, float *dcoords, bool wgrads,
-                         hipStream_t s, void *dout16, float *dbf, bool lat_bias) {
+                         hipStream_t s, void *dout16, float *dbf, bool lat_bias, float *colsum_rep, int rep_w) {
   CINEMA_REQUIRE(fused_eligible(d) && d->pk_bs >= 0, "fused_backward_chain: descriptor not planned for the fused path");
+  if (fused_bwd_wide(d) && !fused_saved_fp8())     // the stream is packed for the wide kernel then (fused_pack_args)
+    return wide_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, dout16, dbf, lat_bias, colsum_rep, rep_w);
   CINEMA_REQUIRE(Npad % FUSED_TS == 0, "fused_backward_chain: Npad %ld not a multiple of %d", (long)Npad, FUSED_TS);
   FusedBwdArgs a = {};
   a.stream = (const bf16_t *)packed + d->pk_bs;

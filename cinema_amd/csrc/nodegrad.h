@@ -23,17 +23,22 @@
 //   dU     bf16 [Rp][F], dUo16 bf16 [Rp][16], dUo32 fp32 [Rp][16]
 //   dcn    fp32 [nparts][Npad][4]   per-(tensor, column group) parts of d coords through the interpolation weights
 //   dT     fp32 [dt_parts][Rp][LP]  per-(segment, k piece) parts of d (node rows), dt_parts = 2 n_mod * dtk (+ 1: final_linear term)
+//   rep    fp32 [NG_REP][rep_w]     replicas of the chain kernel's column sums (b_l gradients [n_layers][HP], then the first
+//                                   layer's weight gradient [HP][4]): workgroup b adds into replica b % NG_REP instead of 256
+//                                   workgroups into one address; k_ng_tail sums them into the flat gradient and clears them
 #pragma once
 #include "common.h"
 
 #define NG_SLOTS 32
 #define NG_ONE_SLOT 31
+#define NG_REP 16
 
 struct NgPlan {
   long S, Npad, Rp;
   int n_mod, F, nparts, ncg, HP, LP, dt_parts;
   int layer_of[CINEMA_MAX_LAYERS];
-  size_t offs, T, Tc, wt, wrow, axt, Up, Vp, dU, dUo16, dUo32, dcn, dT, bytes;
+  size_t offs, T, Tc, wt, wrow, axt, Up, Vp, dU, dUo16, dUo32, dcn, dT, rep, bytes;
+  int rep_w;
 };
 bool ng_eligible(const cinema_siren_desc *d, int lx, int ly, int lz);
 NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad);

@@ -434,7 +434,26 @@ struct NgTailArgs {
   const float *dT; long part_stride; int nseg, LP, C, G, cond_dims; float *dlatents, *dcond; int g_tab, tab_cs;
   // embedding-table gradient
   const float *coords, *dcoords, *dcn, *embed; float *dembed; const int32_t *offs; long N, Npad, S; int tf_dim, nparts, g_tf;
+  // column-sum replicas of the chain kernel (nodegrad.h: rep)
+  float *rep; int rep_w, n_layers, in_dim, g_rep; long off_b[CINEMA_MAX_LAYERS], off_w0;
 };
+
+// thread = one b_l or first-layer weight gradient element: the sum of its NG_REP replicas joins the flat gradient, the
+// replicas are cleared for the next step
+__device__ __forceinline__ void ng_tail_rep(const NgTailArgs &a, int vb) {
+  const int e = vb * 256 + threadIdx.x, nb = a.n_layers * a.H;
+  if (e >= nb + a.H * a.in_dim) return;
+  int src; long dst;
+  if (e < nb) { const int l = e / a.H, f = e - l * a.H; src = l * a.HP + f; dst = a.off_b[l] + f; }
+  else { const int q = e - nb, f = q / a.in_dim, k = q - f * a.in_dim; src = a.n_layers * a.HP + f * 4 + k; dst = a.off_w0 + q; }
+  float v[NG_REP];
+#pragma unroll
+  for (int r = 0; r < NG_REP; ++r) v[r] = a.rep[(long)r * a.rep_w + src];
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < NG_REP; ++r) { t += v[r]; a.rep[(long)r * a.rep_w + src] = 0.f; }
+  a.gp[dst] += t;
+}
 
 // workgroup = 32 columns of dU x 8 groups of subjects: a thread requests its subjects' rows eight at a time (one thread
 // per column walked S dependent-latency loads in a row and paced the whole launch)
@@ -584,7 +603,9 @@ __global__ __launch_bounds__(256) void k_ng_tail(NgTailArgs a) {
   b -= a.g_red;
   if (b < a.g_tab) { if (!(a.skip & 2)) ng_tail_table(a, b); return; }
   b -= a.g_tab;
-  if (!(a.skip & 8)) ng_tail_bias(a, b);
+  if (b < a.g_bias) { if (!(a.skip & 8)) ng_tail_bias(a, b); return; }
+  b -= a.g_bias;
+  ng_tail_rep(a, b);
 }
 
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -628,6 +649,8 @@ NgPlan ng_plan(const cinema_siren_desc *d, int64_t S, int64_t Npad) {
   p.dcn = take((size_t)p.nparts * Npad * 4 * 4);
   p.dt_parts = p.nparts;                     // k_node_grad leaves one part of d (node rows) per workgroup kind
   p.dT = take((size_t)p.dt_parts * p.Rp * d->LP * 4);
+  p.rep_w = (d->n_layers + 4) * d->HP;
+  p.rep = take((size_t)NG_REP * p.rep_w * 4);
   p.bytes = o;
   return p;
 }
@@ -739,7 +762,12 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   for (int j = 0; j < p.n_mod; ++j) a.layer_of[j] = p.layer_of[j];
   for (int i = 0; i < d->n_layers; ++i) a.off_bl[i] = d->off_bl[i];
   a.S = p.S; a.Npad = p.Npad; a.N = (long)t.N;
-  if (t.grad_params != nullptr) { a.gp = t.grad_params; a.g_bias = (p.F + 31) / 32; }
+  if (t.grad_params != nullptr) {
+    a.gp = t.grad_params; a.g_bias = (p.F + 31) / 32;
+    a.rep = (float *)(w + p.rep); a.rep_w = p.rep_w; a.n_layers = d->n_layers; a.in_dim = d->in_dim; a.off_w0 = d->off_w[0];
+    for (int i = 0; i < d->n_layers; ++i) a.off_b[i] = d->off_b[i];
+    a.g_rep = (d->n_layers * d->hidden + d->hidden * d->in_dim + 255) / 256;
+  }
   if (t.dlatents != nullptr) {
     a.dT = (const float *)(w + p.dT); a.part_stride = p.Rp * (long)d->LP; a.nseg = p.dt_parts; a.LP = d->LP;
     a.C = t.C; a.G = t.G; a.cond_dims = t.cond_dims; a.dlatents = t.dlatents; a.dcond = t.dcond;
@@ -752,7 +780,7 @@ int ng_launch_tail(const cinema_siren_desc *d, const NgPlan &p, void *work, cons
   }
   static const int tail_skip = getenv("CINEMA_NG_TAIL_SKIP") ? atoi(getenv("CINEMA_NG_TAIL_SKIP")) : 0;   // developer timing only
   a.skip = tail_skip;
-  const int grid = a.g_red + a.g_tab + a.g_tf + a.g_bias;
+  const int grid = a.g_red + a.g_tab + a.g_tf + a.g_bias + a.g_rep;
   if (grid == 0) return 0;
   hipLaunchKernelGGL(k_ng_tail, dim3((unsigned)grid), dim3(256), 0, s, a);
   CINEMA_CHECK_HIP(hipGetLastError());

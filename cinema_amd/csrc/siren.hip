@@ -1082,9 +1082,15 @@ static int backward_impl(const cinema_siren_desc *d, const float *params, const 
       if (int rc = nodes_backward_chain(d, packed, coords_t, nodes->wrows, nodes->tiles, nodes->U, nodes->S, saved, dout, N, Npad,
                                         gbuf, gp, dcoords, wgrads, nodes->round_s, s, d16, dbf))
         return rc;
-    } else if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, d16, dbf,
-                                             /*lat_bias=*/ng == nullptr))
-      return rc;
+    } else {
+      // node gradients: the chain kernel's column sums go through the replicas of the work buffer (k_ng_tail adds them up)
+      NgPlan rp = {};
+      if (ng != nullptr) rp = ng_plan(d, ng->S, Npad);
+      float *rep = (ng != nullptr && wgrads) ? (float *)((char *)ng->work + rp.rep) : nullptr;
+      if (int rc = fused_backward_chain(d, packed, coords_t, saved, dout, Npad, gbuf, gp, dcoords, wgrads, s, d16, dbf,
+                                        /*lat_bias=*/ng == nullptr, rep, rp.rep_w))
+        return rc;
+    }
     dout_prep_done = prep_rides;
   }
   // ---- node-space reductions of ds / dt / dOut (replace the d-latent GEMM, the linear_lats weight-gradient problems on

@@ -280,6 +280,16 @@ def test_oracle_parity_mixed_chain_tiles(n):
     assert not bad, f"{bad}\nall: {errs}"
 
 
+@pytest.mark.parametrize("n,hidden", [(16500, 512), (20500, 512), (20500, 256)])
+def test_oracle_parity_wide_backward_tile_counts(n, hidden):
+    """bf16, hidden 256 / 512: the wide backward chain (fused_wide.hip) with workgroups of 5 + 4 and of 6 + 5 sample tiles
+    on a 256-CU chip (the bench shape below runs 7 + 6, the small cases above 4), ragged N."""
+    errs = _oracle_case(N=n, S=7, latent_dim=[32, 3, 3, 3], hidden=hidden, layers=3, mod=[1, 3], out_dim=[2, 10], cond=0,
+                        seed=37, precision="bf16", tf_table=True)
+    bad = failing(errs, TOL["bf16"], L2_TOL["bf16"])
+    assert not bad, f"{bad}\nall: {errs}"
+
+
 def test_oracle_parity_full_bench_shape():
     """The configuration the bench line is quoted on, at full size (BASELINE.json cfg-D: latent 256 x 3^3, hidden 512,
     5 hidden layers, modulated 1/3/5, out 2 + 10, 64 subjects, n_samples = 25 000), bf16, against the CPU oracle:

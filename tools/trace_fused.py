@@ -35,6 +35,34 @@ def run():
         eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)
 
 
+if mode == "wide":
+    fw = lib.cinema_debug_wide_trace
+    fw.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    for blk, wave in ((0, 0), (0, 7), (int(os.environ.get("BLK", "200")), 3)):
+        for _ in range(3):
+            eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)
+        torch.cuda.synchronize()
+        fw(blk, wave, None)
+        eng.backward(N, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN)
+        torch.cuda.synchronize()
+        buf = (C.c_longlong * 128)()
+        fw(-1, 0, buf)
+        t = list(buf)
+        print(f"--- wide backward block {blk} wave {wave}: total {(t[127] - t[125]) / 100:.1f} us; prologue {(t[126] - t[125]) / 100:.2f}")
+        prev = t[126]
+        tot = [0.0] * 6
+        for l in range(5, -1, -1):
+            v = [t[8 * l + k] for k in range(6)]
+            names_w = ["GEMM 0", "epilogue 0", "GEMM 1", "barrier A", "epilogue 1", "barrier B"]
+            parts = []
+            for k in range(6):
+                parts.append(f"{names_w[k]} {(v[k] - prev) / 100:.2f}")
+                tot[k] += (v[k] - prev) / 100
+                prev = v[k]
+            print(f"   layer {l}: " + ", ".join(parts))
+        print("   sums: " + ", ".join(f"{n} {x:.1f}" for n, x in zip(names_w, tot)) + f"; tail {(t[127] - prev) / 100:.2f}")
+    sys.exit(0)
+
 for blk, wave in ((0, 0), (0, 7), (int(os.environ.get("BLK", "300")), 3)):
     for _ in range(3):
         run()
