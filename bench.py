@@ -214,8 +214,9 @@ def rooflines(trainer, n, opt, peak):
         ms = event_ms(lambda: eng.forward(n), reps)
         objs.append(obj("k_fused_fwd", "forward stack incl. final_linear", "mfma", 2 * mac_fwd, "flop_per_sample", ms, ["k_fused_fwd"]))
         ms = event_ms(lambda: eng.backward(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_CHAIN), reps)
-        objs.append(obj("k_fused_bwd", "backward chain: dX of every layer", "mfma", 2 * (mac_main + mac_first + H * od),
-                        "flop_per_sample", ms, ["k_fused_bwd"]))
+        # hidden 256 / 512: k_fused_bwdw (fused_wide.hip: workgroups of up to 112 samples); the name filter matches both
+        objs.append(obj("k_fused_bwdw" if d.HP in (256, 512) else "k_fused_bwd", "backward chain: dX of every layer", "mfma",
+                        2 * (mac_main + mac_first + H * od), "flop_per_sample", ms, ["k_fused_bwd"]))
         ms = event_ms(lambda: eng.backward_nodegrad(n, ws.dout, weight_grads=True, phases=_lib.BWD_PHASE_DW,
                                                     **ng_args), reps)
         objs.append(obj("k_dw256 + k_ng_tail", "all weight-gradient GEMMs (linear_lats on S*32 node rows) + split reduction, table / "

@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "siren.hip", "fused.hip", "fused_nodes.hip", "fused_wide.hip", "node.hip", "nodegrad.hip", "trilerp.hip", "loss.hip", "optim.hip"]
-HEADERS = ["common.h", "gemm_engine.h", "fused.h", "fused_dev.h", "nodes.h", "nodegrad.h", "node_device.h", "k1_device.h", "step_device.h", "dw_device.h", "noderows_device.h", "ngprep_device.h", os.path.join("..", "..", "include", "cinema_hip.h")]
+HEADERS = ["common.h", "gemm_engine.h", "fused.h", "fused_dev.h", "nodes.h", "nodegrad.h", "node_device.h", "k1_device.h", "step_device.h", "dw_device.h", "wide_dev.h", "noderows_device.h", "ngprep_device.h", os.path.join("..", "..", "include", "cinema_hip.h")]
 OUT = os.path.join(_HERE, "libcinema_hip.so")
 
 
