@@ -351,7 +351,10 @@ int cinema_siren_backward_nodes(const cinema_siren_desc *d /* host */, const flo
  * instead of N sample rows and  d coords[n] += sum_k dwn[n][k] d w[n][k] / d coords  (no per-sample d-latent rows,
  * no per-sample latent reduction).  Same function as the per-sample calls; different rounding (bf16 interpolation
  * weights and node sums).
- *   work: cinema_nodegrad_work_bytes(d, S, Npad) bytes of device memory, zeroed once by the caller.
+ *   work: cinema_nodegrad_work_bytes(d, S, Npad) bytes of device memory, zeroed once by the caller.  Besides the node
+ *     tables it carries 16 replicas of the chain kernel's column sums (b_l and first-layer weight gradients, hidden 256 /
+ *     512): the CHAIN stage adds into them, the DW stage's tail sums them into grad_params and clears them -- a call with
+ *     the CHAIN bit alone leaves those gradients there until a call that runs the DW stage.
  *   cinema_nodegrad_prepare: per step, after the weights were packed (cinema_siren_pack_part with bits 2 | 8, or
  *     cinema_step_head) -- interpolation weights of the batch, node rows and centred node projections of the current
  *     table (`latents` (S, C, lx, ly, lz): the table K1 interpolates; cond_subject [S x cond_dims] or NULL).
