@@ -56,7 +56,6 @@ struct WideBwdArgs {
   float om_first, om_hidden;
   int trace_block, trace_wave;
   float *rep; int rep_w;             // column-sum replicas (nodegrad.h) or NULL: atomics straight into gp
-  int stagger;                       // start delay per phase group in 100 MHz ticks (see wide_stagger_ticks)
 };
 
 // Epilogue of one pass (fragment pair FP: features fb + 64 FP .. + 7 of this lane, 64 contiguous bytes per row and lane
@@ -312,10 +311,6 @@ template <int BIG, int XS, bool LATB>
 __global__ __launch_bounds__(512) void k_fused_bwdw(WideBwdArgs a) {
   // behind the chain workgroups: the dOut preparation of the weight-gradient launch (reads dOut only)
   if ((int)blockIdx.x >= a.g_chain) { dout_prep_body<bf16_t>(a.fin, a.dout16, blockIdx.x - a.g_chain, a.g_fin); return; }
-  if (a.stagger > 0) {
-    const long long t_go = (long long)wall_clock64() + (long long)(((int)blockIdx.x >> 3) & 3) * a.stagger;
-    while ((long long)wall_clock64() < t_go) __builtin_amdgcn_s_sleep(32);
-  }
   if ((int)blockIdx.x < a.g_big) wide_bwd_body<BIG, XS, LATB>(a, 16L * BIG * blockIdx.x);
   else wide_bwd_body<BIG - 1, XS, LATB>(a, 16L * BIG * a.g_big + 16L * (BIG - 1) * ((int)blockIdx.x - a.g_big));
 }
@@ -342,14 +337,6 @@ extern "C" int cinema_debug_wide_trace(int block, int wave, long long *host_out1
   g_wtrace_block = block; g_wtrace_wave = wave;
   if (host_out128) CINEMA_CHECK_HIP(hipMemcpyFromSymbol(host_out128, HIP_SYMBOL(g_wide_trace), sizeof(long long) * 128));
   return 0;
-}
-
-// A single chip filling of identical workgroups runs in lockstep: every CU is in its MFMA phase (HBM idle) or in its
-// epilogue (HBM saturated) at the same time, and the two add up.  Workgroups therefore start in four phase groups, this many
-// microseconds apart (CINEMA_BWD_STAGGER_US).
-static int wide_stagger_ticks() {
-  static const int v = [] { const char *e = getenv("CINEMA_BWD_STAGGER_US"); const double x = e ? atof(e) : 0.0; return (int)(x * 100.0); }();
-  return v;
 }
 
 static int wide_max_tiles() {
@@ -417,7 +404,6 @@ int wide_backward_chain(const cinema_siren_desc *d, const void *packed, const fl
   a.out_dim = d->out_dim; a.xsteps = ksteps_w(d->HP); a.xrow = 64 * a.xsteps;
   a.om_first = d->omega_first; a.om_hidden = d->omega_hidden;
   a.trace_block = g_wtrace_block; a.trace_wave = g_wtrace_wave;
-  a.stagger = wide_stagger_ticks();
   a.rep = wgrads ? colsum_rep : nullptr; a.rep_w = rep_w;
   int big, g_small;
   wide_launch_plan(Npad, wide_max_tiles(), &big, &a.g_big, &g_small);
