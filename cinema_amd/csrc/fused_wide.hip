@@ -6,12 +6,14 @@
 // every CU pays two streams.  The backward needs no latent rows in LDS, so its g tile can hold 112 samples -- what stops
 // the 64-feature x 112-sample accumulator block of a wave is the register file (112 + 64 ring registers + the epilogue's
 // temporaries: 90-225 spills in fused_nodes.hip's 7-tile variants, whose scratch traffic drains the ring every step).
-// Here a wave takes its 64 output features in TWO passes of 32 (fragment pairs of the pair-major feature map, nodes.h):
+// Here a wave takes its 64 output features in TWO passes of 32 (one fragment pair each; feature map: wide_bwd_body):
 // 56 accumulator registers, the ring holds eight steps of two fragments (the same 16 KB in flight per wave), and the
 // registers this frees carry (a) the first pass's dz chunks until the g tile may be overwritten and (b) the saved rows of
 // the next two sample tiles, requested before the current tile's stores are issued: gfx9 retires loads and stores through
 // ONE in-order counter, so a wait for a tile's rows used to be a wait for every older store as well (DESIGN.md section 7,
 // round 2).  The first pass's epilogue runs before the layer's barrier, i.e. beside the other waves' MFMA phases.
+// Column sums (bias and first-layer weight gradients) go through the replicas of nodegrad.h when the caller has them;
+// the first layer's d coords / dW0 are a tail phase on the dz_0 tile in LDS.
 #include "fused.h"
 #include "gemm_engine.h"
 #include "nodegrad.h"
@@ -27,6 +29,7 @@ namespace {
 
 #define WIDE_LA_MOD 2             // sample tiles whose saved rows (c, z, s) are requested ahead of the one being processed
 #define WIDE_LA_PLAIN 4           // the same for unmodulated layers (c only)
+
 // optional phase trace of one wave (tools/trace_fused.py MODE=wide): 100 MHz timestamps
 __device__ long long g_wide_trace[128];
 #ifdef FUSED_TRACE_BUILD   // perturbs register allocation: only in the libcinema_hip_trace.so developer build
@@ -36,11 +39,8 @@ __device__ long long g_wide_trace[128];
 #define WIDE_TRACE(ID)
 #endif
 
-#ifdef WIDE_NT_STORES
-#define WIDE_STORE(P, V) __builtin_nontemporal_store(V, reinterpret_cast<bf16x8 *>(P))
-#else
+// (non-temporal stores, __builtin_nontemporal_store, measured here: 240 us against 235)
 #define WIDE_STORE(P, V) *reinterpret_cast<bf16x8 *>(P) = V
-#endif
 
 struct WideBwdArgs {
   FinalBwdArgs fin; bf16_t *dout16; int g_chain, g_fin;   // tail workgroups: dOut -> [Npad x 16] bf16 + final bias gradient
@@ -59,8 +59,9 @@ struct WideBwdArgs {
 };
 
 // Epilogue of one pass (fragment pair FP: features fb + 64 FP .. + 7 of this lane, 64 contiguous bytes per row and lane
-// group, the other half of the 128-byte line belongs to the neighbouring wave): dz = omega * dy * c (* s), ds = omega * dy * c * z, dt = dy * c.  FP == 0 leaves its dz chunks in `hold` (the g
-// tile is still being read); FP == 1 runs behind the layer's barrier and writes both passes' chunks.
+// group, the other half of the 128-byte line belongs to the neighbouring wave): dz = omega * dy * c (* s),
+// ds = omega * dy * c * z, dt = dy * c.  FP == 0 leaves its dz chunks in `hold` (the g tile is still being read); FP == 1
+// runs behind the layer's barrier and writes both passes' chunks.
 template <bool MOD, int FP, int NST, bool LATB>
 __device__ __forceinline__ void wide_epilogue(const WideBwdArgs &a, f32x4 (&acc)[2][NST], bf16x8 (&hold)[NST], int l,
                                               float omega, long n0, unsigned toff_l, unsigned tstep, unsigned fb_l, int i_l,
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512) void k_fused_bwdw(WideBwdArgs a) {
 // ========================================================================================
 static inline int ksteps_w(int k) { return ((k / 32) + FUSED_RING - 1) / FUSED_RING * FUSED_RING; }
 
-// The wide kernel reads the backward stream in the pair-major feature map, so the choice is a function of the descriptor
+// The wide kernel reads the backward stream in its own feature map (wide_bwd_body), so the choice is a function of the descriptor
 // (and the process-wide switch) only: fused_pack_args and fused_backward_chain both ask here.  CINEMA_BWD_WIDE=0 keeps
 // k_fused_bwd (A/B switch).
 bool fused_bwd_wide(const cinema_siren_desc *d) {
